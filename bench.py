@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the RBM CD-1 hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): CD-1 Gibbs-steps/sec on a 784-visible x 1024-hidden RBM at batch 4096,
+fp32, synthetic binary data resident in HBM.  One "step" (the unit of `value`) = one full CD-1
+parameter update over 4096 rows: h_pos sample, v_neg sample, h_neg probabilities, dW / db_h / db_v
+applied (update_mode "fused").  With N > 1 every rank processes its own 4096 rows per step (weak
+scaling: global batch 4096 N, config 3 at N = 8), the packed [dW|db_h|db_v] sums are all-reduced
+over RCCL, and `value` counts N units per global step.
+
+The line also carries `roofline` (per-launch fp32-MFMA fraction of the dominant kernel, HIP-event
+timed on the launch stream) and `cpu_baseline` (the numpy oracle of the same step timed on this
+host's cores; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_VIS, N_HID, BATCH = 784, 1024, 4096
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CU x 256 flop/clk x 2.4 GHz
+FLOP_HALF = 2.0 * BATCH * N_VIS * N_HID            # one half-step GEMM
+FLOP_OUTER = 4.0 * BATCH * N_VIS * N_HID           # statistics GEMM: k = 2 x batch
+FLOP_STEP = 3 * FLOP_HALF + FLOP_OUTER             # 10 B V H
+
+
+def event_time_ms(fn, iters, warm=3):
+    """Average duration of fn() in ms by HIP events on torch's current stream (= the launch stream)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / iters
+
+
+def cpu_baseline():
+    """The oracle's fused CD-1 step (numpy + OpenBLAS) on the host cores, bounded sample."""
+    from oracle import rbm_oracle as O
+    from oracle.make_golden import synthetic_binary, synthetic_params
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    W, b_h, b_v = synthetic_params(N_VIS, N_HID, seed=1)
+    v = synthetic_binary(BATCH, N_VIS, seed=1234)
+    O.cd_step_fused(W, b_h, b_v, v, 1e-3 / BATCH, 42, 0)      # warm
+    n, t0 = 0, time.perf_counter()
+    while n < 5 or (time.perf_counter() - t0 < 10.0 and n < 40):
+        W, b_h, b_v, _, _ = O.cd_step_fused(W, b_h, b_v, v, 1e-3 / BATCH, 42, n + 1)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "steps/s", "cores": int(cores), "kind": "port",
+            "sample": "%d fused CD-1 steps of oracle/rbm_oracle.py (numpy sgemm + numpy Philox), 784x1024, B=4096" % n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                     "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from keras_unsupervised_amd.ebm import dp
+    from keras_unsupervised_amd.ebm.engine import DeviceMatrix, DeviceRBM
+
+    # synthetic workload, resident in HBM before the timed region
+    g = np.random.default_rng(1)
+    W = g.uniform(-0.05, 0.05, size=(N_VIS, N_HID)).astype(np.float32)
+    eng = DeviceRBM(W, np.zeros(N_HID, np.float32), np.zeros(N_VIS, np.float32), device)
+    n_batches = 16
+    u = eng.philox_uniform(n_batches * BATCH, N_VIS, 1234 + rank, 0x7004, 0)
+    V = DeviceMatrix((u.t < 0.19).to(torch.float32).contiguous(), n_batches * BATCH, N_VIS, u.ld)
+    del u
+    lr = 1e-3 / BATCH            # keeps the weights finite over long runs; throughput does not depend on lr
+    seed = 42
+
+    def step(i):
+        lo = (i % n_batches) * BATCH
+        if world == 1:
+            eng.cd_step(V, BATCH, lo, lr, seed, i)
+        else:
+            eng.cd_step(V, BATCH, lo, lr, seed, i, apply=False, emit_delta=True, row0=rank * BATCH)
+            dp.allreduce_sum_(eng.delta_buffer())
+            eng.apply_delta(lr)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(eng.W.t).all().item()), "weights diverged"
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        # per-kernel durations (HIP events on the launch stream), each launched alone
+        h_pos = eng.half_step("vh", V, BATCH, 0, 0, 1, seed, 0, 0)["sample"]
+        v_neg = eng.half_step("hv", h_pos, BATCH, 0, 0, 1, seed, 1, 0)["sample"]
+        h_neg = eng.half_step("vh", v_neg, BATCH, 0, 0, 0, seed, 0, 0, want_sample=False, want_prob=True)["prob"]
+        import ctypes as C
+        from keras_unsupervised_amd import _lib
+        ws = eng.workspace(BATCH)
+        rng = _lib.Rng(seed, 0, 0, 0)
+        o_h = DeviceMatrix.zeros(BATCH, N_HID, device)
+        o_v = DeviceMatrix.zeros(BATCH, N_VIS, device)
+        dW = torch.empty((N_VIS, N_HID), dtype=torch.float32, device=device)
+        st = lambda: C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        lib, ctx, P = eng.lib, eng.ctx.handle, C.byref(eng.params)
+        k_vh = lambda: _lib.check(lib.kurbm_half_step_vh(ctx, P, V.ptr(), BATCH, V.ld, 0, 1, C.byref(rng), o_h.ptr(), None, o_h.ld, st()))
+        k_hv = lambda: _lib.check(lib.kurbm_half_step_hv(ctx, P, h_pos.ptr(), BATCH, h_pos.ld, 0, 1, C.byref(rng), o_v.ptr(), None, o_v.ld, st()))
+        k_vhp = lambda: _lib.check(lib.kurbm_half_step_vh(ctx, P, v_neg.ptr(), BATCH, v_neg.ld, 0, 0, None, None, o_h.ptr(), o_h.ld, st()))
+        k_out = lambda: _lib.check(lib.kurbm_outer_delta(ctx, V.ptr(), h_pos.ptr(), v_neg.ptr(), h_neg.ptr(), BATCH, N_VIS, N_HID,
+                                                         V.ld, h_pos.ld, dW.data_ptr(), ws.data_ptr(), ws.numel(), st()))
+        kern = {}
+        for name, fn, flop in (("half_step_vh_sample", k_vh, FLOP_HALF), ("half_step_hv_sample", k_hv, FLOP_HALF),
+                               ("half_step_vh_prob", k_vhp, FLOP_HALF), ("outer_stats_plus_reduce", k_out, FLOP_OUTER)):
+            ms = event_time_ms(fn, 50)
+            kern[name] = {"ms": ms, "tflops": flop / (ms * 1e-3) / 1e12, "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        step_tflops = FLOP_STEP / (ms_per_step * 1e-3) / 1e12
+        out = {
+            "metric": "cd1_gibbs_steps_per_sec", "value": value,
+            "unit": "steps/s (1 step = CD-1 update over 4096 rows, 784x1024 fp32)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "rbm_784x1024_cd1_batch4096_fp32 (BASELINE.json configs[1]%s)" % ("" if world == 1 else "; configs[2] shape: 4096 rows per GPU"),
+                       "n_vis": N_VIS, "n_hid": N_HID, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
+                       "cd_k": 1, "update_mode": "fused", "lr": "1e-3/4096", "parallelism": "dp%d" % world,
+                       "flop_per_step": FLOP_STEP},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": kern[dom]["frac"], "traffic": None,
+                         "kernels": kern, "step_tflops": step_tflops * world, "step_frac": step_tflops / PEAK_F32_MFMA_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/*
+ * kurbm.h -- C ABI of the MI355X (gfx950) RBM / DBN contrastive-divergence engine.
+ *
+ * This is the drop-in boundary for the hot path of tonandr/keras_unsupervised's
+ * ku/ebm package.  The reference has no FFI of its own: its narrowest seam is the set of
+ * seven K.function closures an RBM object owns (reference ku/ebm/rbm.py:48, :54, :76,
+ * :127, :129, :132, :137) plus its three variables (rbm.py:30-40).  Each entry point
+ * below cites the closure(s) it replaces.  The Python classes in
+ * keras_unsupervised_amd/ebm bind these with ctypes (see INTEGRATION.md for the stub a
+ * reference maintainer would add).
+ *
+ * Conventions (all entry points)
+ *   - every pointer named v/h/W/b_*, out_*, delta, workspace is a DEVICE pointer into
+ *     caller-owned memory; the library never allocates or frees device memory and never
+ *     synchronises with the host;
+ *   - matrices are row-major fp32 [rows, ld]; ld is in floats, ld % 4 == 0, ld >= columns;
+ *     base addresses are 16-byte aligned.  Columns [cols, ld) are padding: inputs may hold
+ *     anything there, outputs are left untouched there;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - return value: 0 = KURBM_OK, < 0 = error; kurbm_last_error() returns a thread-local
+ *     message for the last failing call on this thread;
+ *   - a kurbm_ctx belongs to one device and must not be used from two threads at once.
+ *
+ * Random numbers: Philox4x32-10, key = (seed_lo, seed_hi),
+ *   counter = (col, (row0 + row) >> 2, stream_id, step), word (row0 + row) & 3,
+ *   u = bitcast_f32((word & 0x7FFFFF) | 0x3F800000) - 1.0f.   row0 % 4 == 0 is required.
+ *   Normals (Gaussian visible units): Box-Muller over the planes stream_id and
+ *   stream_id | 0x80000000.  The CPU statement of the same contract is oracle/philox.py.
+ */
+#ifndef KURBM_H
+#define KURBM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KURBM_ABI_VERSION 1
+
+typedef struct kurbm_ctx kurbm_ctx;
+typedef void* kurbm_stream_t; /* hipStream_t */
+
+enum {
+    KURBM_OK = 0,
+    KURBM_ERR_ARG = -1,         /* bad pointer / shape / alignment */
+    KURBM_ERR_HIP = -2,         /* a HIP runtime call failed */
+    KURBM_ERR_UNSUPPORTED = -3, /* valid request this build does not implement */
+    KURBM_ERR_WORKSPACE = -4    /* workspace too small */
+};
+
+/* Activation applied to the pre-activation x = in.W(+T) + bias. */
+enum {
+    KURBM_ACT_SIGMOID = 0, /* Bernoulli units: rbm.py:47, :53, :124 */
+    KURBM_ACT_RELU = 1,    /* Gaussian-mode hidden threshold: rbm.py:59, :86 */
+    KURBM_ACT_LINEAR = 2   /* Gaussian visible mean: rbm.py:64-65, :143 */
+};
+
+/* What is drawn from the activated value p. */
+enum {
+    KURBM_NOISE_NONE = 0,      /* no draw: only out_prob is written (h_neg, rbm.py:124) */
+    KURBM_NOISE_BERNOULLI = 1, /* out_sample = (u < p) ? 1 : 0   (rbm.py:46-47, :121-123) */
+    KURBM_NOISE_GAUSSIAN = 2   /* out_sample = p + z, z ~ N(0,1) (rbm.py:64-66, :143-144) */
+};
+
+/* RBM.mode of the reference (rbm.py:14-16). */
+enum { KURBM_MODE_VISIBLE_BERNOULLI = 0, KURBM_MODE_VISIBLE_GAUSSIAN = 1 };
+
+/* The three variables of an RBM (rbm.py:30-40), resident on the device. */
+typedef struct {
+    int32_t n_vis;  /* rows of W */
+    int32_t n_hid;  /* columns of W */
+    int32_t ldw;    /* leading dimension of W in floats */
+    int32_t _pad;
+    float* W;       /* [n_vis, ldw]  rbm_weight      rbm.py:30-33 */
+    float* b_h;     /* [n_hid]       rbm_hidden_bias rbm.py:34-37 */
+    float* b_v;     /* [n_vis]       visible_bias    rbm.py:38-40 */
+} kurbm_params;
+
+/* One sampling site of the RNG contract. */
+typedef struct {
+    uint64_t seed;
+    uint64_t row0;      /* global index of the first row; multiple of 4 */
+    uint32_t stream_id;
+    uint32_t step;
+} kurbm_rng;
+
+/* Options of one contrastive-divergence parameter update. */
+typedef struct {
+    int32_t k;          /* Gibbs iterations (reference: 1)                          */
+    int32_t mode;       /* KURBM_MODE_*                                             */
+    float lr;           /* hps['lr'], applied to batch SUMS (rbm.py:128,130,133)    */
+    int32_t apply;      /* 1: W,b_h,b_v += lr*delta in place; 0: only emit delta    */
+    float* delta_out;   /* nullable; packed [n_vis*n_hid | n_hid | n_vis] fp32 sums */
+    float* v_chain;     /* nullable; persistent chain [rows, ldv], read then overwritten
+                           with v_neg (extension; absent from the reference)         */
+    uint64_t seed;
+    uint64_t row0;      /* global row offset of this shard (data parallel); % 4 == 0 */
+    uint32_t step;      /* parameter-update counter                                  */
+    uint32_t chain;     /* chain id: stream ids are chain*64 + {2t, 2t-1}            */
+} kurbm_cd_opts;
+
+/* ---- context ------------------------------------------------------------------- */
+int kurbm_abi_version(void);
+const char* kurbm_last_error(void);
+int kurbm_ctx_create(int device, kurbm_ctx** out);
+void kurbm_ctx_destroy(kurbm_ctx* ctx);
+
+/* ---- RNG test hook: out[r, c] = u(row0 + r, c) under the contract above -------- */
+int kurbm_philox_uniform(kurbm_ctx* ctx, float* out, int rows, int cols, int ld,
+                         const kurbm_rng* rng, kurbm_stream_t stream);
+
+/*
+ * visible -> hidden half step.   Replaces transform_func (rbm.py:46-48 / :58-60), the body
+ * of RBM.call (rbm.py:80-86) and, with noise = NONE, the h_neg expression (rbm.py:124).
+ *   x = v.W + b_h ; p = act(x) ; out_prob = p (nullable) ; out_sample per `noise` (nullable)
+ * ONE kernel launch: MFMA GEMM + fused bias / activation / Philox draw epilogue.
+ */
+int kurbm_half_step_vh(kurbm_ctx* ctx, const kurbm_params* p, const float* v, int rows, int ldv,
+                       int act, int noise, const kurbm_rng* rng,
+                       float* out_sample, float* out_prob, int ldh, kurbm_stream_t stream);
+
+/*
+ * hidden -> visible half step.   Replaces inv_transform_func (rbm.py:52-54 / :64-67) and
+ * the v_neg expression of the CD graph (rbm.py:121-123 / :143-144).  W is read as stored
+ * (never transposed in memory):   x = h.W^T + b_v.
+ */
+int kurbm_half_step_hv(kurbm_ctx* ctx, const kurbm_params* p, const float* h, int rows, int ldh,
+                       int act, int noise, const kurbm_rng* rng,
+                       float* out_sample, float* out_prob, int ldv, kurbm_stream_t stream);
+
+/* Test hooks: the same launches, additionally writing the uniforms that were compared
+ * against the probabilities (out_u, nullable, same shape/ld as the outputs). */
+int kurbm_half_step_vh_dbg(kurbm_ctx* ctx, const kurbm_params* p, const float* v, int rows, int ldv,
+                           int act, int noise, const kurbm_rng* rng, float* out_sample,
+                           float* out_prob, float* out_u, int ldh, kurbm_stream_t stream);
+int kurbm_half_step_hv_dbg(kurbm_ctx* ctx, const kurbm_params* p, const float* h, int rows, int ldh,
+                           int act, int noise, const kurbm_rng* rng, float* out_sample,
+                           float* out_prob, float* out_u, int ldv, kurbm_stream_t stream);
+
+/* Bytes of scratch kurbm_cd_step / kurbm_free_energy need for batches of <= rows. */
+size_t kurbm_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int k);
+
+/*
+ * One CD-k parameter update from one Gibbs chain.   Replaces rbm_weight_update_func,
+ * hidden_bias_update_func and visible_bias_update_func (rbm.py:125-134) evaluated on ONE
+ * chain (update_mode "fused"); `chain` selects an independent chain so the host can also
+ * replay the reference's three-chain sequence (rbm.py:214-216).
+ * Launch sequence: half_vh(sample) ; k x [half_hv(sample) ; half_vh] ; outer-product
+ * split-K GEMM over [v_pos ; -v_neg]^T.[h_pos ; h_neg] ; reduce (+ apply).
+ * `which` is a bit mask of what `apply` touches: 1 = W, 2 = b_h, 4 = b_v (7 = all).
+ */
+int kurbm_cd_step(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, int rows, int ldv,
+                  const kurbm_cd_opts* opts, int which, void* workspace, size_t workspace_bytes,
+                  kurbm_stream_t stream);
+
+/* params += lr * delta for a packed delta (after the data-parallel all-reduce). */
+int kurbm_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, const float* delta, float lr,
+                      int which, kurbm_stream_t stream);
+
+/*
+ * Free energy F(v) = -(v.b_v + sum_j softplus((v.W + b_h)_j)).   Replaces
+ * free_energy_func (rbm.py:73-76), with the overflow-free softplus.
+ */
+int kurbm_free_energy(kurbm_ctx* ctx, const kurbm_params* p, const float* v, int rows, int ldv,
+                      float* F, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
+/*
+ * Sufficient-statistics GEMM alone (bench / test hook for the dominant kernel):
+ *   delta[0 : n_vis*n_hid] = v_pos^T.h_pos - v_neg^T.h_neg   (dense, ld = n_hid)
+ */
+int kurbm_outer_delta(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, const float* v_neg,
+                      const float* h_neg, int rows, int n_vis, int n_hid, int ldv, int ldh,
+                      float* delta_w, void* workspace, size_t workspace_bytes,
+                      kurbm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KURBM_H */

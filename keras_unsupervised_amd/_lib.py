@@ -1,0 +1,103 @@
+"""ctypes binding of ``libkurbm.so`` (C ABI: ``include/kurbm.h``).
+
+There is no CPU fallback: if the shared library is missing or a call fails the
+product raises.  ``load()`` only dlopens the library (works without a GPU, so the CPU
+test tier can check the exported symbols); a context needs a gfx950 device.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkurbm.so")
+
+KURBM_OK = 0
+ACT_SIGMOID, ACT_RELU, ACT_LINEAR = 0, 1, 2
+NOISE_NONE, NOISE_BERNOULLI, NOISE_GAUSSIAN = 0, 1, 2
+WHICH_W, WHICH_BH, WHICH_BV, WHICH_ALL = 1, 2, 4, 7
+
+
+class KurbmError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("n_vis", C.c_int32), ("n_hid", C.c_int32), ("ldw", C.c_int32), ("_pad", C.c_int32),
+                ("W", C.c_void_p), ("b_h", C.c_void_p), ("b_v", C.c_void_p)]
+
+
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("row0", C.c_uint64), ("stream_id", C.c_uint32), ("step", C.c_uint32)]
+
+
+class CdOpts(C.Structure):
+    _fields_ = [("k", C.c_int32), ("mode", C.c_int32), ("lr", C.c_float), ("apply", C.c_int32),
+                ("delta_out", C.c_void_p), ("v_chain", C.c_void_p),
+                ("seed", C.c_uint64), ("row0", C.c_uint64), ("step", C.c_uint32), ("chain", C.c_uint32)]
+
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+_PP, _RP, _OP = C.POINTER(Params), C.POINTER(Rng), C.POINTER(CdOpts)
+
+# name -> (restype, argtypes); every symbol include/kurbm.h declares
+SIGNATURES = {
+    "kurbm_abi_version": (_i, []),
+    "kurbm_last_error": (C.c_char_p, []),
+    "kurbm_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "kurbm_ctx_destroy": (None, [_vp]),
+    "kurbm_philox_uniform": (_i, [_vp, _vp, _i, _i, _i, _RP, _vp]),
+    "kurbm_half_step_vh": (_i, [_vp, _PP, _vp, _i, _i, _i, _i, _RP, _vp, _vp, _i, _vp]),
+    "kurbm_half_step_hv": (_i, [_vp, _PP, _vp, _i, _i, _i, _i, _RP, _vp, _vp, _i, _vp]),
+    "kurbm_half_step_vh_dbg": (_i, [_vp, _PP, _vp, _i, _i, _i, _i, _RP, _vp, _vp, _vp, _i, _vp]),
+    "kurbm_half_step_hv_dbg": (_i, [_vp, _PP, _vp, _i, _i, _i, _i, _RP, _vp, _vp, _vp, _i, _vp]),
+    "kurbm_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "kurbm_cd_step": (_i, [_vp, _PP, _vp, _i, _i, _OP, _i, _vp, _sz, _vp]),
+    "kurbm_apply_delta": (_i, [_vp, _PP, _vp, C.c_float, _i, _vp]),
+    "kurbm_free_energy": (_i, [_vp, _PP, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "kurbm_outer_delta": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libkurbm.so and type its entry points.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KurbmError(
+            "HIP library %s is missing; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C keras_unsupervised_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != KURBM_OK:
+        msg = load().kurbm_last_error()
+        raise KurbmError("kurbm error %d: %s" % (code, msg.decode() if msg else "?"))
+
+
+class Context:
+    """One kurbm_ctx per device."""
+
+    _cache = {}
+
+    def __init__(self, device_index):
+        lib = load()
+        h = _vp()
+        check(lib.kurbm_ctx_create(int(device_index), C.byref(h)))
+        self.handle = h
+        self.device_index = int(device_index)
+        self.lib = lib
+
+    @classmethod
+    def get(cls, device_index):
+        ctx = cls._cache.get(device_index)
+        if ctx is None:
+            ctx = cls._cache[device_index] = cls(device_index)
+        return ctx

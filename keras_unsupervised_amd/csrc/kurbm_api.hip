@@ -1,0 +1,432 @@
+// kurbm_api.hip -- the extern "C" boundary declared in include/kurbm.h.
+//
+// Host-side planning (tile configuration, split-K factor, workspace carving) and the launch
+// sequences; all arithmetic is in kurbm_kernels.hip.  No allocation, no host synchronisation.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/kurbm.h"
+#include "kurbm_kernels.h"
+
+using namespace kurbm;
+
+struct kurbm_ctx {
+    int device;
+    int ncu;
+};
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(KURBM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static bool bad_matrix(const void* p, int ld, int cols) { return !p || !aligned16(p) || ld % 4 != 0 || ld < cols; }
+
+static int check_params(const kurbm_params* p) {
+    if (!p) return fail(KURBM_ERR_ARG, "params is null");
+    if (p->n_vis <= 0 || p->n_hid <= 0) return fail(KURBM_ERR_ARG, "n_vis/n_hid must be positive");
+    if (bad_matrix(p->W, p->ldw, p->n_hid)) return fail(KURBM_ERR_ARG, "W: null, misaligned, or ldw %% 4 != 0 / ldw < n_hid");
+    if (!p->b_h || !p->b_v) return fail(KURBM_ERR_ARG, "bias pointer is null");
+    return KURBM_OK;
+}
+
+static RngArgs make_rng(uint64_t seed, uint64_t row0, uint32_t stream_id, uint32_t step) {
+    RngArgs r;
+    r.seed_lo = (uint32_t)(seed & 0xFFFFFFFFu);
+    r.seed_hi = (uint32_t)(seed >> 32);
+    r.stream_id = stream_id;
+    r.step = step;
+    r.row0 = row0;
+    return r;
+}
+
+// ---- planning -------------------------------------------------------------------------
+// cost of covering an M x N output with one configuration: full waves of workgroups over the
+// CUs times the tile area (every workgroup runs the same k extent).
+static int pick_cfg(int ncu, int M, int N, int* gm_out, int* gn_out) {
+    int best = 0;
+    long long best_cost = -1, best_blocks = 0;
+    for (int c = 0; c < CFG_COUNT; ++c) {
+        int bm, bn;
+        tile_shape(c, &bm, &bn);
+        const long long blocks = (long long)ceil_div(M, bm) * ceil_div(N, bn);
+        const long long waves = (blocks + ncu - 1) / ncu;
+        const long long cost = waves * bm * bn;
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && blocks < best_blocks)) {
+            best = c; best_cost = cost; best_blocks = blocks;
+        }
+    }
+    int bm, bn;
+    tile_shape(best, &bm, &bn);
+    *gm_out = ceil_div(M, bm);
+    *gn_out = ceil_div(N, bn);
+    return best;
+}
+
+struct OuterPlan { int cfg, gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_split, ld_slab; };
+
+// statistics GEMM: output n_vis x n_hid, k = batch rows (two signed segments)
+static OuterPlan plan_outer(int ncu, int rows, int n_vis, int n_hid) {
+    OuterPlan pl;
+    // tile by least padded area (independent of rows so the slab count is monotone in rows)
+    long long best = -1;
+    pl.cfg = 0; pl.gm = pl.gn = 1;
+    for (int c = 0; c < CFG_COUNT; ++c) {
+        int bm, bn;
+        tile_shape(c, &bm, &bn);
+        const int gm = ceil_div(n_vis, bm), gn = ceil_div(n_hid, bn);
+        const long long area = (long long)gm * gn * bm * bn;
+        if (best < 0 || area < best) { best = area; pl.cfg = c; pl.gm = gm; pl.gn = gn; }
+    }
+    pl.nkt = ceil_div(rows, 32);
+    pl.kt_total = 2 * pl.nkt;
+    const int tiles = pl.gm * pl.gn;
+    int s = ncu / tiles;
+    if (s < 1) s = 1;
+    if (s > pl.kt_total) s = pl.kt_total;
+    pl.nsplit_bound = s;  // monotone in rows: what the workspace reserves
+    pl.kt_per_split = ceil_div(pl.kt_total, s);
+    pl.nsplit = ceil_div(pl.kt_total, pl.kt_per_split);
+    pl.ld_slab = round_up(n_hid, 4);
+    return pl;
+}
+
+struct Workspace {
+    float *h_pos, *h_neg, *h_tmp, *v_neg, *part_h, *part_v, *slab;
+    int ldh, ldv, ld_part_h, ld_part_v, max_row_tiles;
+    size_t slab_stride, bytes;
+};
+
+static size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
+
+static Workspace carve(int ncu, void* base, int rows, int n_vis, int n_hid, int k) {
+    Workspace w;
+    w.ldh = round_up(n_hid, 4);
+    w.ldv = round_up(n_vis, 4);
+    w.max_row_tiles = ceil_div(rows, 112);
+    w.ld_part_h = w.ldh;
+    w.ld_part_v = w.ldv;
+    const OuterPlan pl = plan_outer(ncu, rows, n_vis, n_hid);
+    w.slab_stride = (size_t)n_vis * pl.ld_slab;
+    size_t off = 0;
+    char* b = static_cast<char*>(base);
+    auto take = [&](size_t nfloat) { float* p = reinterpret_cast<float*>(b + off); off = align_up(off + nfloat * 4); return p; };
+    w.h_pos = take((size_t)rows * w.ldh);
+    w.h_neg = take((size_t)rows * w.ldh);
+    w.h_tmp = take((size_t)rows * w.ldh);   // intermediate h_t (k > 1) / persistent-chain start
+    w.v_neg = take((size_t)rows * w.ldv);
+    w.part_h = take((size_t)w.max_row_tiles * w.ld_part_h);
+    w.part_v = take((size_t)w.max_row_tiles * w.ld_part_v);
+    w.slab = take(w.slab_stride * pl.nsplit_bound);
+    (void)k;
+    // free energy: row partials [col tiles][round_up(rows,4)] alias the front of the workspace
+    const size_t fe = align_up((size_t)ceil_div(n_hid, 112) * round_up(rows, 4) * 4);
+    w.bytes = off > fe ? off : fe;
+    return w;
+}
+
+// ---- the half step ---------------------------------------------------------------------
+static int half_step(kurbm_ctx* ctx, int layout, const kurbm_params* p, const float* in, int rows, int ld_in,
+                     int act, int noise, const RngArgs* rng, float* out_sample, float* out_prob, float* out_u,
+                     int ldo, const float* ref, int ldref, float* colpart, int ld_colpart, int* grid_m_out,
+                     hipStream_t st) {
+    const int K = (layout == LAYOUT_VH) ? p->n_vis : p->n_hid;
+    const int N = (layout == LAYOUT_VH) ? p->n_hid : p->n_vis;
+    if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
+    if (bad_matrix(in, ld_in, K)) return fail(KURBM_ERR_ARG, "input: null, misaligned, ld %% 4 != 0 or ld < columns");
+    if (act < ACT_SIGMOID || act > ACT_LINEAR) return fail(KURBM_ERR_ARG, "unknown activation %d", act);
+    if (noise < NOISE_NONE || noise > NOISE_GAUSSIAN) return fail(KURBM_ERR_ARG, "unknown noise %d", noise);
+    if (!out_sample && !out_prob) return fail(KURBM_ERR_ARG, "both outputs are null");
+    if (noise != NOISE_NONE && !rng) return fail(KURBM_ERR_ARG, "rng is null");
+    if (noise != NOISE_NONE && (rng->row0 & 3)) return fail(KURBM_ERR_ARG, "rng.row0 must be a multiple of 4");
+    if (noise == NOISE_NONE && out_sample && !out_prob) { out_prob = out_sample; out_sample = nullptr; }
+    if ((out_sample && bad_matrix(out_sample, ldo, N)) || (out_prob && bad_matrix(out_prob, ldo, N)))
+        return fail(KURBM_ERR_ARG, "output: misaligned, ld %% 4 != 0 or ld < columns");
+
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A0 = in; g.lda = ld_in;
+    g.B0 = p->W; g.ldb = p->ldw;
+    g.M = rows; g.N = N; g.K = K;
+    g.nkt = ceil_div(K, 32);
+    g.kt_total = g.nkt; g.kt_per_split = g.nkt; g.nsplit = 1;
+    const int cfg = pick_cfg(ctx->ncu, rows, N, &g.grid_m, &g.grid_n);
+    g.bias = (layout == LAYOUT_VH) ? p->b_h : p->b_v;
+    g.out_sample = out_sample; g.out_prob = out_prob; g.out_u = out_u; g.ldo = ldo;
+    g.ref = ref; g.ldref = ldref; g.colpart = colpart; g.ld_colpart = ld_colpart;
+    g.act = act; g.noise = noise;
+    if (rng) g.rng = *rng;
+    if (grid_m_out) *grid_m_out = g.grid_m;
+    HIP_TRY(launch_gemm(layout, cfg, EPI_HALFSTEP, g, st));
+    return KURBM_OK;
+}
+
+static int outer_slabs(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, const float* v_neg, const float* h_neg,
+                       int rows, int n_vis, int n_hid, int ldv, int ldh, float* slab, size_t slab_stride,
+                       const OuterPlan& pl, hipStream_t st) {
+    (void)ctx;
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A0 = v_pos; g.A1 = v_neg; g.lda = ldv;
+    g.B0 = h_pos; g.B1 = h_neg; g.ldb = ldh;
+    g.M = n_vis; g.N = n_hid; g.K = rows;
+    g.nkt = pl.nkt; g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
+    g.grid_m = pl.gm; g.grid_n = pl.gn;
+    g.slab = slab; g.slab_stride = slab_stride; g.ld_slab = pl.ld_slab;
+    HIP_TRY(launch_gemm(LAYOUT_OUTER, pl.cfg, EPI_SLAB, g, st));
+    return KURBM_OK;
+}
+
+// ---- C ABI -----------------------------------------------------------------------------
+extern "C" {
+
+int kurbm_abi_version(void) { return KURBM_ABI_VERSION; }
+
+const char* kurbm_last_error(void) { return g_err.c_str(); }
+
+int kurbm_ctx_create(int device, kurbm_ctx** out) {
+    if (!out) return fail(KURBM_ERR_ARG, "out is null");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(KURBM_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(KURBM_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    kurbm_ctx* c = new kurbm_ctx;
+    c->device = device;
+    c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c;
+    return KURBM_OK;
+}
+
+void kurbm_ctx_destroy(kurbm_ctx* ctx) { delete ctx; }
+
+int kurbm_philox_uniform(kurbm_ctx* ctx, float* out, int rows, int cols, int ld, const kurbm_rng* rng,
+                         kurbm_stream_t stream) {
+    if (!ctx || !out || !rng) return fail(KURBM_ERR_ARG, "null argument");
+    if (rows <= 0 || cols <= 0 || ld < cols) return fail(KURBM_ERR_ARG, "bad shape");
+    if (rng->row0 & 3) return fail(KURBM_ERR_ARG, "rng.row0 must be a multiple of 4");
+    const RngArgs r = make_rng(rng->seed, rng->row0, rng->stream_id, rng->step);
+    HIP_TRY(launch_philox_uniform(out, rows, cols, ld, r, static_cast<hipStream_t>(stream)));
+    return KURBM_OK;
+}
+
+int kurbm_half_step_vh(kurbm_ctx* ctx, const kurbm_params* p, const float* v, int rows, int ldv, int act, int noise,
+                       const kurbm_rng* rng, float* out_sample, float* out_prob, int ldh, kurbm_stream_t stream) {
+    return kurbm_half_step_vh_dbg(ctx, p, v, rows, ldv, act, noise, rng, out_sample, out_prob, nullptr, ldh, stream);
+}
+
+int kurbm_half_step_hv(kurbm_ctx* ctx, const kurbm_params* p, const float* h, int rows, int ldh, int act, int noise,
+                       const kurbm_rng* rng, float* out_sample, float* out_prob, int ldv, kurbm_stream_t stream) {
+    return kurbm_half_step_hv_dbg(ctx, p, h, rows, ldh, act, noise, rng, out_sample, out_prob, nullptr, ldv, stream);
+}
+
+int kurbm_half_step_vh_dbg(kurbm_ctx* ctx, const kurbm_params* p, const float* v, int rows, int ldv, int act,
+                           int noise, const kurbm_rng* rng, float* out_sample, float* out_prob, float* out_u, int ldh,
+                           kurbm_stream_t stream) {
+    if (!ctx) return fail(KURBM_ERR_ARG, "ctx is null");
+    if (int e = check_params(p)) return e;
+    RngArgs r;
+    if (rng) r = make_rng(rng->seed, rng->row0, rng->stream_id, rng->step);
+    return half_step(ctx, LAYOUT_VH, p, v, rows, ldv, act, noise, rng ? &r : nullptr, out_sample, out_prob, out_u, ldh,
+                     nullptr, 0, nullptr, 0, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int kurbm_half_step_hv_dbg(kurbm_ctx* ctx, const kurbm_params* p, const float* h, int rows, int ldh, int act,
+                           int noise, const kurbm_rng* rng, float* out_sample, float* out_prob, float* out_u, int ldv,
+                           kurbm_stream_t stream) {
+    if (!ctx) return fail(KURBM_ERR_ARG, "ctx is null");
+    if (int e = check_params(p)) return e;
+    RngArgs r;
+    if (rng) r = make_rng(rng->seed, rng->row0, rng->stream_id, rng->step);
+    return half_step(ctx, LAYOUT_HV, p, h, rows, ldh, act, noise, rng ? &r : nullptr, out_sample, out_prob, out_u, ldv,
+                     nullptr, 0, nullptr, 0, nullptr, static_cast<hipStream_t>(stream));
+}
+
+size_t kurbm_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int k) {
+    if (!ctx || rows <= 0 || n_vis <= 0 || n_hid <= 0) return 0;
+    return carve(ctx->ncu, nullptr, rows, n_vis, n_hid, k).bytes;
+}
+
+int kurbm_cd_step(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, int rows, int ldv,
+                  const kurbm_cd_opts* o, int which, void* workspace, size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx || !o) return fail(KURBM_ERR_ARG, "null argument");
+    if (int e = check_params(p)) return e;
+    if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
+    if (bad_matrix(v_batch, ldv, p->n_vis)) return fail(KURBM_ERR_ARG, "v_batch: null, misaligned, ld %% 4 != 0 or ld < n_vis");
+    if (o->k < 1 || o->k > 15) return fail(KURBM_ERR_ARG, "k must be in [1, 15]");
+    if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN)
+        return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
+    if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
+    if (!workspace || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "workspace is null or misaligned");
+    if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Workspace w = carve(ctx->ncu, workspace, rows, p->n_vis, p->n_hid, o->k);
+    if (w.bytes > workspace_bytes)
+        return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+
+    const bool gauss = (o->mode == KURBM_MODE_VISIBLE_GAUSSIAN);
+    const int act_h = gauss ? ACT_RELU : ACT_SIGMOID;             // rbm.py:59 vs :47
+    const int act_v = gauss ? ACT_LINEAR : ACT_SIGMOID;           // rbm.py:64-65 vs :53
+    const int noise_v = gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI;
+    const uint32_t base = o->chain * 64u;
+    const bool need_w = (which & 1) || o->delta_out;
+    int e;
+
+    // h_pos ~ p(h | v_pos)                                        rbm.py:120 (self.transform)
+    RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
+    if ((e = half_step(ctx, LAYOUT_VH, p, v_batch, rows, ldv, act_h, NOISE_BERNOULLI, &r, w.h_pos, nullptr, nullptr,
+                       w.ldh, nullptr, 0, nullptr, 0, nullptr, st)))
+        return e;
+    const float* h_cur = w.h_pos;
+    if (o->v_chain) {  // persistent chain: the negative phase starts from the stored fantasy
+        r = make_rng(o->seed, o->row0, base + 32u, o->step);
+        if ((e = half_step(ctx, LAYOUT_VH, p, o->v_chain, rows, ldv, act_h, NOISE_BERNOULLI, &r, w.h_tmp, nullptr,
+                           nullptr, w.ldh, nullptr, 0, nullptr, 0, nullptr, st)))
+            return e;
+        h_cur = w.h_tmp;
+    }
+    // the final v sample is written straight into the persistent chain when there is one
+    float* v_last = o->v_chain ? o->v_chain : w.v_neg;
+    int gm_v = 0, gm_h = 0;
+    for (int t = 1; t <= o->k; ++t) {
+        const bool last = (t == o->k);
+        // v_t ~ p(v | h_{t-1})                                    rbm.py:121-123 / :143-144
+        r = make_rng(o->seed, o->row0, base + 2u * t - 1u, o->step);
+        float* v_out = last ? v_last : w.v_neg;
+        if ((e = half_step(ctx, LAYOUT_HV, p, h_cur, rows, w.ldh, act_v, noise_v, &r, v_out, nullptr, nullptr, ldv,
+                           last ? v_batch : nullptr, ldv, w.part_v, w.ld_part_v, last ? &gm_v : nullptr, st)))
+            return e;
+        if (!last) {
+            r = make_rng(o->seed, o->row0, base + 2u * t, o->step);
+            if ((e = half_step(ctx, LAYOUT_VH, p, v_out, rows, ldv, act_h, NOISE_BERNOULLI, &r, w.h_tmp, nullptr, nullptr,
+                               w.ldh, nullptr, 0, nullptr, 0, nullptr, st)))
+                return e;
+            h_cur = w.h_tmp;
+        }
+    }
+    // h_neg = sigmoid(v_neg.W + b_h): probabilities, sigmoid in both modes   rbm.py:124 / :145
+    if ((e = half_step(ctx, LAYOUT_VH, p, v_last, rows, ldv, ACT_SIGMOID, NOISE_NONE, nullptr, nullptr, w.h_neg, nullptr,
+                       w.ldh, w.h_pos, w.ldh, w.part_h, w.ld_part_h, &gm_h, st)))
+        return e;
+
+    // dW = v_pos^T.h_pos - v_neg^T.h_neg  (rbm.py:125-126) as split-K slabs
+    const OuterPlan pl = plan_outer(ctx->ncu, rows, p->n_vis, p->n_hid);
+    if (need_w)
+        if ((e = outer_slabs(ctx, v_batch, w.h_pos, v_last, w.h_neg, rows, p->n_vis, p->n_hid, ldv, w.ldh, w.slab,
+                             w.slab_stride, pl, st)))
+            return e;
+
+    // reduce slabs / bias partials, apply lr * sums (rbm.py:127-134) and/or emit the packed delta
+    ReduceArgs a;
+    memset(&a, 0, sizeof a);
+    a.slab = w.slab; a.slab_stride = w.slab_stride; a.nslab = pl.nsplit; a.ld_slab = pl.ld_slab;
+    a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw;
+    a.nblk_w = need_w ? (int)(((long long)p->n_vis * (pl.ld_slab / 4) + 255) / 256) : 0;
+    a.lr = o->lr;
+    const bool ap = o->apply != 0;
+    a.W = (ap && (which & 1)) ? p->W : nullptr;
+    a.delta_w = o->delta_out;
+    a.part_h = w.part_h; a.nrow_tiles_h = gm_h; a.ld_part_h = w.ld_part_h;
+    a.b_h = (ap && (which & 2)) ? p->b_h : nullptr;
+    a.delta_bh = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid : nullptr;
+    a.part_v = w.part_v; a.nrow_tiles_v = gm_v; a.ld_part_v = w.ld_part_v;
+    a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
+    a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
+    HIP_TRY(launch_reduce_apply(a, st));
+    return KURBM_OK;
+}
+
+int kurbm_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, const float* delta, float lr, int which,
+                      kurbm_stream_t stream) {
+    if (!ctx || !delta) return fail(KURBM_ERR_ARG, "null argument");
+    if (int e = check_params(p)) return e;
+    ApplyArgs a;
+    a.delta = delta;
+    a.W = (which & 1) ? p->W : nullptr;
+    a.b_h = (which & 2) ? p->b_h : nullptr;
+    a.b_v = (which & 4) ? p->b_v : nullptr;
+    a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw; a.lr = lr;
+    HIP_TRY(launch_apply_delta(a, static_cast<hipStream_t>(stream)));
+    return KURBM_OK;
+}
+
+int kurbm_free_energy(kurbm_ctx* ctx, const kurbm_params* p, const float* v, int rows, int ldv, float* F,
+                      void* workspace, size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx || !F) return fail(KURBM_ERR_ARG, "null argument");
+    if (int e = check_params(p)) return e;
+    if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
+    if (bad_matrix(v, ldv, p->n_vis)) return fail(KURBM_ERR_ARG, "v: null, misaligned, ld %% 4 != 0 or ld < n_vis");
+    if (!workspace || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "workspace is null or misaligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A0 = v; g.lda = ldv; g.B0 = p->W; g.ldb = p->ldw;
+    g.M = rows; g.N = p->n_hid; g.K = p->n_vis;
+    g.nkt = ceil_div(g.K, 32); g.kt_total = g.nkt; g.kt_per_split = g.nkt; g.nsplit = 1;
+    const int cfg = pick_cfg(ctx->ncu, rows, g.N, &g.grid_m, &g.grid_n);
+    g.bias = p->b_h;
+    g.rowpart = static_cast<float*>(workspace);
+    g.ld_rowpart = round_up(rows, 4);
+    const size_t need = (size_t)g.grid_n * g.ld_rowpart * 4;
+    if (need > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    HIP_TRY(launch_gemm(LAYOUT_VH, cfg, EPI_SOFTPLUS, g, st));
+    FinishArgs f;
+    f.v = v; f.b_v = p->b_v; f.rowpart = g.rowpart; f.F = F;
+    f.rows = rows; f.n_vis = p->n_vis; f.ldv = ldv; f.ncol_tiles = g.grid_n; f.ld_rowpart = g.ld_rowpart;
+    HIP_TRY(launch_free_energy_finish(f, st));
+    return KURBM_OK;
+}
+
+int kurbm_outer_delta(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, const float* v_neg, const float* h_neg,
+                      int rows, int n_vis, int n_hid, int ldv, int ldh, float* delta_w, void* workspace,
+                      size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx || !delta_w) return fail(KURBM_ERR_ARG, "null argument");
+    if (rows <= 0 || n_vis <= 0 || n_hid <= 0) return fail(KURBM_ERR_ARG, "bad shape");
+    if (bad_matrix(v_pos, ldv, n_vis) || bad_matrix(v_neg, ldv, n_vis) || bad_matrix(h_pos, ldh, n_hid) ||
+        bad_matrix(h_neg, ldh, n_hid))
+        return fail(KURBM_ERR_ARG, "operand: null, misaligned, ld %% 4 != 0 or ld < columns");
+    if (!workspace || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "workspace is null or misaligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Workspace w = carve(ctx->ncu, workspace, rows, n_vis, n_hid, 1);
+    if (w.bytes > workspace_bytes)
+        return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    const OuterPlan pl = plan_outer(ctx->ncu, rows, n_vis, n_hid);
+    if (int e = outer_slabs(ctx, v_pos, h_pos, v_neg, h_neg, rows, n_vis, n_hid, ldv, ldh, w.slab, w.slab_stride, pl, st))
+        return e;
+    ReduceArgs a;
+    memset(&a, 0, sizeof a);
+    a.slab = w.slab; a.slab_stride = w.slab_stride; a.nslab = pl.nsplit; a.ld_slab = pl.ld_slab;
+    a.n_vis = n_vis; a.n_hid = n_hid; a.ldw = 0;
+    a.nblk_w = (int)(((long long)n_vis * (pl.ld_slab / 4) + 255) / 256);
+    a.delta_w = delta_w;
+    a.n_hid = n_hid;
+    // no bias work: n_hid/n_vis bias blocks see null partial pointers and do nothing
+    HIP_TRY(launch_reduce_apply(a, st));
+    return KURBM_OK;
+}
+
+}  // extern "C"

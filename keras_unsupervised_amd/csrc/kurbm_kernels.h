@@ -1,0 +1,98 @@
+// kurbm_kernels.h -- argument blocks shared by the kernels and the C-ABI host layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kurbm {
+
+enum { ACT_SIGMOID = 0, ACT_RELU = 1, ACT_LINEAR = 2 };
+enum { NOISE_NONE = 0, NOISE_BERNOULLI = 1, NOISE_GAUSSIAN = 2 };
+enum { EPI_HALFSTEP = 0, EPI_SLAB = 1, EPI_SOFTPLUS = 2 };
+// operand layouts: VH  A=[m][k] B=[k][n];  HV  A=[m][k] B=[n][k];  OUTER  A=[k][m] B=[k][n]
+enum { LAYOUT_VH = 0, LAYOUT_HV = 1, LAYOUT_OUTER = 2 };
+enum { CFG_128x128 = 0, CFG_128x112 = 1, CFG_112x128 = 2, CFG_COUNT = 3 };
+
+struct RngArgs {
+    uint32_t seed_lo, seed_hi;
+    uint32_t stream_id, step;
+    uint64_t row0;
+};
+
+struct GemmArgs {
+    // operands; segment 1 (A1,B1) enters with sign -1 (statistics GEMM only)
+    const float* A0;
+    const float* B0;
+    const float* A1;
+    const float* B1;
+    int lda, ldb;
+    int M, N, K;        // K = extent of k per segment
+    int nkt;            // k-tiles per segment  = ceil(K / 32)
+    int kt_total;       // k-tiles over all segments
+    int kt_per_split;   // k-tiles per split-K slice
+    int nsplit;
+    int grid_m, grid_n;
+    // half-step epilogue
+    const float* bias;
+    float* out_sample;
+    float* out_prob;
+    float* out_u;       // debug: the uniforms used (nullable)
+    int ldo;
+    const float* ref;   // nullable: column partials of (ref - out) are written to colpart
+    int ldref;
+    float* colpart;     // [grid_m][ld_colpart]
+    int ld_colpart;
+    int act, noise;
+    RngArgs rng;
+    // slab epilogue
+    float* slab;        // [nsplit][M][ld_slab]
+    size_t slab_stride;
+    int ld_slab;
+    // softplus epilogue
+    float* rowpart;     // [grid_n][ld_rowpart]
+    int ld_rowpart;
+};
+
+struct ReduceArgs {
+    const float* slab;
+    size_t slab_stride;
+    int nslab, ld_slab;
+    int n_vis, n_hid, ldw;
+    int nblk_w;
+    float lr;
+    float* W;           // nullable: W += lr * dW
+    float* delta_w;     // nullable: dense [n_vis][n_hid]
+    const float* part_h;
+    int nrow_tiles_h, ld_part_h;
+    float* b_h;
+    float* delta_bh;
+    const float* part_v;
+    int nrow_tiles_v, ld_part_v;
+    float* b_v;
+    float* delta_bv;
+};
+
+struct ApplyArgs {
+    const float* delta;
+    float* W;
+    float* b_h;
+    float* b_v;
+    int n_vis, n_hid, ldw;
+    float lr;
+};
+
+struct FinishArgs {
+    const float* v;
+    const float* b_v;
+    const float* rowpart;
+    float* F;
+    int rows, n_vis, ldv, ncol_tiles, ld_rowpart;
+};
+
+void tile_shape(int cfg, int* bm, int* bn);
+hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g, hipStream_t st);
+hipError_t launch_philox_uniform(float* out, int rows, int cols, int ld, const RngArgs& rng, hipStream_t st);
+hipError_t launch_reduce_apply(const ReduceArgs& a, hipStream_t st);
+hipError_t launch_apply_delta(const ApplyArgs& a, hipStream_t st);
+hipError_t launch_free_energy_finish(const FinishArgs& a, hipStream_t st);
+
+}  // namespace kurbm

@@ -1,0 +1,526 @@
+// kurbm_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the RBM contrastive-divergence path.
+//
+// One templated fp32 MFMA GEMM core (v_mfma_f32_16x16x4_f32, exact f32 fma chains) with
+// three operand-layout variants and fused epilogues:
+//
+//   half step v->h   x = v.W + b_h      A = v  [row][k] (k contiguous)   B = W [k][n]
+//   half step h->v   x = h.W^T + b_v    A = h  [row][k]                  B = W [n][k]  (W read
+//                                                                        as stored, never transposed)
+//   statistics       dW = v+^T.h+ - v-^T.h-   A = v [k][m], B = h [k][n], K = batch, two signed
+//                                       segments, split over the batch into fp32 slabs
+//
+// Reference op sequences replaced (reference ku/ebm/rbm.py): :46-47 / :82-83 (v->h),
+// :52-53 / :121-123 (h->v), :124 (h_neg), :125-134 (updates), :73-75 (free energy).
+//
+// Design notes (DESIGN.md has the long form):
+//   * 256 threads = 4 waves per workgroup, one wave per SIMD; every wave owns a WM x WN
+//     output tile as TM x TN accumulators of 16x16 (4 VGPRs each).
+//   * K is consumed in tiles of 32.  Operands whose k index is contiguous in memory are
+//     staged "x-major" ([x][36]); a lane fetches 4 consecutive k with one ds_read_b128 and
+//     feeds them to 4 successive MFMAs.  The MFMA sums over k, so any pairing of k between
+//     the four k-slots of a 16x16x4 is valid as long as A and B agree: both use
+//     k(r, slot, t) = 16 r + 4 slot + t.  Operands whose k index is the slow one are staged
+//     "k-major" ([k][BX+4]) and read with ds_read_b32 at that same k.
+//   * Global -> register -> LDS staging, two LDS buffers, one barrier per k-tile; the
+//     loads of tile t+2 are issued before the MFMAs of tile t.
+//   * The Philox block of an output element is keyed by (col, row >> 2): its four words are
+//     the four rows a lane holds in one 16x16 accumulator, so one Philox call serves one
+//     accumulator and no lane computes a block it does not use.
+//   * Column sums needed by the bias updates are produced deterministically as per-row-tile
+//     partials by the epilogue (no atomics anywhere: results are bit-reproducible).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kurbm_kernels.h"
+
+namespace kurbm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;          // k-tile
+constexpr int NTHREADS = 256;   // 4 waves
+constexpr int LDX = BK + 4;     // x-major LDS row (floats): 144 B, 16-B aligned, conflict-free b128
+
+// ------------------------------------------------------------------------------------
+// Philox4x32-10 (Random123 constants) -- same contract as oracle/philox.py
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u32_to_unit(uint32_t x) {
+    return __uint_as_float((x & 0x7FFFFFu) | 0x3F800000u) - 1.0f;
+}
+
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+    return __fdividef(1.0f, 1.0f + __expf(-x));
+}
+
+__device__ __forceinline__ float softplusf(float x) {
+    return fmaxf(x, 0.0f) + log1pf(__expf(-fabsf(x)));
+}
+
+__global__ void k_philox_uniform(float* __restrict__ out, int rows, int cols, int ld, RngArgs rng) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rg = blockIdx.y;  // group of 4 rows
+    if (col >= cols) return;
+    const uint64_t grow = rng.row0 + (uint64_t)rg * 4;
+    uint32_t w[4];
+    philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), rng.stream_id, rng.step, rng.seed_lo, rng.seed_hi, w);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = rg * 4 + r;
+        if (row < rows) out[(size_t)row * ld + col] = u32_to_unit(w[r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// operand staging: global -> registers -> LDS
+// ------------------------------------------------------------------------------------
+template <int BX, bool KMAJOR>
+struct Stage {
+    static constexpr int LDK = BX + 4;  // k-major LDS row (floats); (BX+4) % 8 == 4 for BX in {112,128}
+    static constexpr int CHUNKS = BX * BK / 4;
+    static constexpr int ITERS = (CHUNKS + NTHREADS - 1) / NTHREADS;
+    static constexpr int TILE_FLOATS = KMAJOR ? BK * LDK : BX * LDX;
+    f32x4 r[ITERS];
+
+    // chunk q of the tile -> (k, x) of its first element; consecutive lanes walk the
+    // contiguous memory direction, so a wave reads whole 128-B (x-major) / 512-B (k-major) runs
+    static __device__ __forceinline__ void coords(int q, int& kk, int& xx) {
+        if (KMAJOR) { kk = q / (BX / 4); xx = 4 * (q % (BX / 4)); }
+        else        { xx = q / (BK / 4); kk = 4 * (q % (BK / 4)); }
+    }
+
+    // Issue the global loads of one tile.  Branch-free on purpose: out-of-range chunks read
+    // element 0 of the matrix (always mapped) and are zeroed in store(); a conditional load
+    // makes hipcc wait vmcnt(0) right behind every load, which serialises the tile's fetches.
+    __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int x0, int X, int k0,
+                                         int kend, int tid) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int q = it * NTHREADS + tid;
+            int kk, xx;
+            coords(q, kk, xx);
+            const int k = k0 + kk, x = x0 + xx;
+            const bool ok = (k < kend) & (x < X) & ((CHUNKS % NTHREADS == 0) | (q < CHUNKS));
+            const size_t off = KMAJOR ? ((size_t)k * ld + x) : ((size_t)x * ld + k);
+            r[it] = *reinterpret_cast<const f32x4*>(src + (ok ? off : (size_t)0));
+        }
+    }
+
+    // Mask what lies outside [0,X) x [0,kend), apply the segment sign, write the LDS tile.
+    __device__ __forceinline__ void store(float* __restrict__ s, int x0, int X, int k0, int kend, float sgn,
+                                          int tid) const {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int q = it * NTHREADS + tid;
+            int kk, xx;
+            coords(q, kk, xx);
+            const int k = k0 + kk, x = x0 + xx;
+            const bool ok = (k < kend) & (x < X);
+            const int lim = KMAJOR ? (X - x) : (kend - k);  // valid elements along the contiguous direction
+            f32x4 v = r[it];
+            v.x = ok ? v.x * sgn : 0.f;
+            v.y = (ok & (lim > 1)) ? v.y * sgn : 0.f;
+            v.z = (ok & (lim > 2)) ? v.z * sgn : 0.f;
+            v.w = (ok & (lim > 3)) ? v.w * sgn : 0.f;
+            if ((CHUNKS % NTHREADS == 0) || q < CHUNKS)
+                *reinterpret_cast<f32x4*>(s + (KMAJOR ? kk * LDK + xx : xx * LDX + kk)) = v;
+        }
+    }
+};
+
+// Fragment fetch for MFMA 16x16x4: element e (0..3) of frag[i] is the operand of the MFMA
+// at k-step (r, e): k = 16 r + 4 (lane >> 4) + e, row/col = x_base + 16 i + (lane & 15).
+template <int BX, bool KMAJOR, int T>
+__device__ __forceinline__ void fetch_frags(const float* __restrict__ s, int xw, int r, int lane,
+                                            f32x4 (&frag)[T]) {
+    const int l15 = lane & 15, slot = lane >> 4;
+    if (KMAJOR) {
+        constexpr int LDK = BX + 4;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const float* p = s + (16 * r + 4 * slot) * LDK + xw + 16 * i + l15;
+            frag[i].x = p[0];
+            frag[i].y = p[LDK];
+            frag[i].z = p[2 * LDK];
+            frag[i].w = p[3 * LDK];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+            frag[i] = *reinterpret_cast<const f32x4*>(s + (xw + 16 * i + l15) * LDX + 16 * r + 4 * slot);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// the GEMM kernel
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int EPI, int NOISE>
+__global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile");
+    using StA = Stage<BM, A_KM>;
+    using StB = Stage<BN, B_KM>;
+    constexpr int A_FL = StA::TILE_FLOATS, B_FL = StB::TILE_FLOATS;
+    constexpr int EPI_FL = (EPI == EPI_HALFSTEP) ? WAVES_M * BN : ((EPI == EPI_SOFTPLUS) ? WAVES_N * BM : 0);
+    constexpr int SMEM_FL = (2 * (A_FL + B_FL) > EPI_FL) ? 2 * (A_FL + B_FL) : EPI_FL;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FL];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // ---- block -> (tile, k-slice): XCD-aware bijective remap (blocks b and b+8 share an XCD,
+    // so give each XCD a contiguous run of tiles: neighbours share the A row panel in its L2)
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    const int tiles_mn = g.grid_m * g.grid_n;
+    const int z = bid / tiles_mn;
+    const int tmn = bid - z * tiles_mn;
+    const int bm = tmn / g.grid_n, bn = tmn - bm * g.grid_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // k-tiles [t_begin, t_end) of the concatenated segments
+    const int nkt = g.nkt;  // k-tiles per segment
+    const int t_begin = z * g.kt_per_split;
+    int t_end = t_begin + g.kt_per_split;
+    if (t_end > g.kt_total) t_end = g.kt_total;
+    const int nt = t_end - t_begin;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    StA sa;
+    StB sb;
+    float* sA0 = smem;
+    float* sB0 = smem + 2 * A_FL;
+
+    // tile t of the concatenated k space -> (segment, k0)
+    auto issue = [&](int t) {
+        const int seg = (t >= nkt) ? 1 : 0;
+        const int k0 = (t - seg * nkt) * BK;
+        sa.load(seg ? g.A1 : g.A0, g.lda, m0, g.M, k0, g.K, tid);
+        sb.load(seg ? g.B1 : g.B0, g.ldb, n0, g.N, k0, g.K, tid);
+    };
+    auto commit = [&](int t, int buf) {
+        const int seg = (t >= nkt) ? 1 : 0;
+        const int k0 = (t - seg * nkt) * BK;
+        sa.store(sA0 + buf * A_FL, m0, g.M, k0, g.K, seg ? -1.0f : 1.0f, tid);
+        sb.store(sB0 + buf * B_FL, n0, g.N, k0, g.K, 1.0f, tid);
+    };
+
+    if (nt > 0) {
+        issue(t_begin);
+        commit(t_begin, 0);
+        __syncthreads();
+        if (nt > 1) issue(t_begin + 1);
+        for (int i = 0; i < nt; ++i) {
+            const int cur = i & 1;
+            // tile i+1 was fetched during the MFMAs of tile i-1; park it in the other buffer
+            if (i + 1 < nt) commit(t_begin + i + 1, cur ^ 1);
+            if (i + 2 < nt) issue(t_begin + i + 2);
+            const float* cA = sA0 + cur * A_FL;
+            const float* cB = sB0 + cur * B_FL;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                f32x4 fa[TM], fb[TN];
+                fetch_frags<BM, A_KM, TM>(cA, wm * WM, r, lane, fa);
+                fetch_frags<BN, B_KM, TN>(cB, wn * WN, r, lane, fb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi][e], fb[ni][e], acc[mi][ni], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    const int l15 = lane & 15, slot = lane >> 4;
+
+    // ---------------- epilogue: raw partial sums to a slab (statistics GEMM) ------------
+    if (EPI == EPI_SLAB) {
+        float* slab = g.slab + (size_t)z * g.slab_stride;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int col = n0 + wn * WN + ni * 16 + l15;
+                const int rowb = m0 + wm * WM + mi * 16 + slot * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rowb + r < g.M && col < g.N) slab[(size_t)(rowb + r) * g.ld_slab + col] = acc[mi][ni][r];
+            }
+        return;
+    }
+
+    // ---------------- epilogue: bias + activation + draw (+ column-difference partials) -
+    if (EPI == EPI_HALFSTEP) {
+        float csum[TN];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) csum[ni] = 0.f;
+        const bool want_diff = (g.ref != nullptr);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = n0 + wn * WN + ni * 16 + l15;
+            const bool cok = col < g.N;
+            const float bias = cok ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int rowb = m0 + wm * WM + mi * 16 + slot * 4;
+                uint32_t w[4], w2[4];
+                if (NOISE != NOISE_NONE) {
+                    const uint64_t grow = g.rng.row0 + (uint64_t)rowb;
+                    philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step,
+                                  g.rng.seed_lo, g.rng.seed_hi, w);
+                    if (NOISE == NOISE_GAUSSIAN)
+                        philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id | 0x80000000u,
+                                      g.rng.step, g.rng.seed_lo, g.rng.seed_hi, w2);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rowb + r;
+                    const float x = acc[mi][ni][r] + bias;
+                    float p;
+                    if (g.act == ACT_SIGMOID) p = sigmoidf_fast(x);
+                    else if (g.act == ACT_RELU) p = fmaxf(x, 0.f);
+                    else p = x;
+                    float s = p;
+                    if (NOISE == NOISE_BERNOULLI) {
+                        s = (u32_to_unit(w[r]) < p) ? 1.0f : 0.0f;
+                    } else if (NOISE == NOISE_GAUSSIAN) {
+                        const float ua = u32_to_unit(w[r]), ub = u32_to_unit(w2[r]);
+                        s = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * ub);
+                    }
+                    if (row < g.M && cok) {
+                        const size_t o = (size_t)row * g.ldo + col;
+                        if (g.out_prob) g.out_prob[o] = p;
+                        if (g.out_sample) g.out_sample[o] = s;
+                        if (g.out_u && NOISE != NOISE_NONE) g.out_u[o] = u32_to_unit(w[r]);
+                        if (want_diff) csum[ni] += g.ref[(size_t)row * g.ldref + col] - s;
+                    }
+                }
+            }
+        }
+        if (want_diff) {
+            // rows of one column live in the 4 lane groups (lane >> 4) and in the WAVES_M waves
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                csum[ni] += __shfl_xor(csum[ni], 16);
+                csum[ni] += __shfl_xor(csum[ni], 32);
+            }
+            // smem is free: the k loop ended on a barrier
+            if (slot == 0) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) smem[wm * BN + wn * WN + ni * 16 + l15] = csum[ni];
+            }
+            __syncthreads();
+            if (tid < BN) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < WAVES_M; ++i) t += smem[i * BN + tid];
+                if (n0 + tid < g.N) g.colpart[(size_t)bm * g.ld_colpart + n0 + tid] = t;
+            }
+        }
+        return;
+    }
+
+    // ---------------- epilogue: softplus row sums (free energy) ------------------------
+    if (EPI == EPI_SOFTPLUS) {
+        float rsum[TM][4];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rsum[mi][r] = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = n0 + wn * WN + ni * 16 + l15;
+            const bool cok = col < g.N;
+            const float bias = cok ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (cok) rsum[mi][r] += softplusf(acc[mi][ni][r] + bias);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = rsum[mi][r];
+                t += __shfl_xor(t, 1);
+                t += __shfl_xor(t, 2);
+                t += __shfl_xor(t, 4);
+                t += __shfl_xor(t, 8);
+                if (l15 == 0) smem[wn * BM + wm * WM + mi * 16 + slot * 4 + r] = t;
+            }
+        __syncthreads();
+        if (tid < BM) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < WAVES_N; ++i) t += smem[i * BM + tid];
+            if (m0 + tid < g.M) g.rowpart[(size_t)bn * g.ld_rowpart + m0 + tid] = t;
+        }
+        return;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// slab reduction (+ parameter update)
+// ------------------------------------------------------------------------------------
+// Blocks [0, nblk_w) sum the split-K slabs of dW (4 columns per thread) and either add
+// lr * dW into W or store dW densely; the blocks after them reduce the bias partials.
+__global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < a.nblk_w) {
+        const int groups = a.ld_slab / 4;  // float4 groups per row
+        const long long q = (long long)blockIdx.x * 256 + tid;
+        if (q >= (long long)a.n_vis * groups) return;
+        const int i = (int)(q / groups), j0 = (int)(q - (long long)i * groups) * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int zz = 0; zz < a.nslab; ++zz)
+            s += *reinterpret_cast<const f32x4*>(a.slab + (size_t)zz * a.slab_stride + (size_t)i * a.ld_slab + j0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            if (j < a.n_hid) {
+                if (a.delta_w) a.delta_w[(size_t)i * a.n_hid + j] = s[e];
+                if (a.W) a.W[(size_t)i * a.ldw + j] += a.lr * s[e];
+            }
+        }
+        return;
+    }
+    const int q = ((int)blockIdx.x - a.nblk_w) * 256 + tid;
+    if (q < a.n_hid) {
+        if (a.part_h) {
+            float t = 0.f;
+            for (int r = 0; r < a.nrow_tiles_h; ++r) t += a.part_h[(size_t)r * a.ld_part_h + q];
+            if (a.delta_bh) a.delta_bh[q] = t;
+            if (a.b_h) a.b_h[q] += a.lr * t;
+        }
+    } else if (q < a.n_hid + a.n_vis) {
+        const int c = q - a.n_hid;
+        if (a.part_v) {
+            float t = 0.f;
+            for (int r = 0; r < a.nrow_tiles_v; ++r) t += a.part_v[(size_t)r * a.ld_part_v + c];
+            if (a.delta_bv) a.delta_bv[c] = t;
+            if (a.b_v) a.b_v[c] += a.lr * t;
+        }
+    }
+}
+
+// params += lr * delta for a packed [V*H | H | V] delta
+__global__ __launch_bounds__(256) void k_apply_delta(ApplyArgs a) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nw = (long long)a.n_vis * a.n_hid;
+    if (q < nw) {
+        if (a.W) {
+            const int i = (int)(q / a.n_hid), j = (int)(q - (long long)i * a.n_hid);
+            a.W[(size_t)i * a.ldw + j] += a.lr * a.delta[q];
+        }
+    } else if (q < nw + a.n_hid) {
+        if (a.b_h) a.b_h[q - nw] += a.lr * a.delta[q];
+    } else if (q < nw + a.n_hid + a.n_vis) {
+        if (a.b_v) a.b_v[q - nw - a.n_hid] += a.lr * a.delta[q];
+    }
+}
+
+// F[row] = -( v[row].b_v + sum over column tiles of the softplus row partials )
+__global__ __launch_bounds__(256) void k_free_energy_finish(FinishArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= a.rows) return;
+    float t = 0.f;
+    for (int c = lane; c < a.n_vis; c += 64) t += a.v[(size_t)row * a.ldv + c] * a.b_v[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) {
+        float sp = 0.f;
+        for (int i = 0; i < a.ncol_tiles; ++i) sp += a.rowpart[(size_t)i * a.ld_rowpart + row];
+        a.F[row] = -(t + sp);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, int WM_, int WN_, bool A_KM, bool B_KM, int EPI, int NOISE>
+static hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
+    const int nblk = g.grid_m * g.grid_n * g.nsplit;
+    hipLaunchKernelGGL((k_gemm<BM, BN, WM_, WN_, A_KM, B_KM, EPI, NOISE>), dim3(nblk), dim3(NTHREADS), 0, st, g);
+    return hipGetLastError();
+}
+
+void tile_shape(int cfg, int* bm, int* bn) {
+    switch (cfg) {
+        case CFG_128x128: *bm = 128; *bn = 128; break;
+        case CFG_128x112: *bm = 128; *bn = 112; break;
+        default: *bm = 112; *bn = 128; break;
+    }
+}
+
+hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g, hipStream_t st) {
+#define KURBM_CASE(L, AK, BKM, E, NZ)                                                               \
+    if (layout == L && epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) {                          \
+        if (cfg == CFG_128x128) return launch_cfg<128, 128, 2, 2, AK, BKM, E, NZ>(g, st);            \
+        if (cfg == CFG_128x112) return launch_cfg<128, 112, 4, 1, AK, BKM, E, NZ>(g, st);            \
+        if (cfg == CFG_112x128) return launch_cfg<112, 128, 1, 4, AK, BKM, E, NZ>(g, st);            \
+    }
+    KURBM_CASE(LAYOUT_VH, false, true, EPI_HALFSTEP, NOISE_NONE)
+    KURBM_CASE(LAYOUT_VH, false, true, EPI_HALFSTEP, NOISE_BERNOULLI)
+    KURBM_CASE(LAYOUT_HV, false, false, EPI_HALFSTEP, NOISE_NONE)
+    KURBM_CASE(LAYOUT_HV, false, false, EPI_HALFSTEP, NOISE_BERNOULLI)
+    KURBM_CASE(LAYOUT_HV, false, false, EPI_HALFSTEP, NOISE_GAUSSIAN)
+    KURBM_CASE(LAYOUT_VH, false, true, EPI_SOFTPLUS, NOISE_NONE)
+    KURBM_CASE(LAYOUT_OUTER, true, true, EPI_SLAB, NOISE_NONE)
+#undef KURBM_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_philox_uniform(float* out, int rows, int cols, int ld, const RngArgs& rng, hipStream_t st) {
+    dim3 grid((cols + 255) / 256, (rows + 3) / 4);
+    hipLaunchKernelGGL(k_philox_uniform, grid, dim3(256), 0, st, out, rows, cols, ld, rng);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_apply(const ReduceArgs& a, hipStream_t st) {
+    const int nb = (a.n_hid + a.n_vis + 255) / 256;
+    hipLaunchKernelGGL(k_reduce_apply, dim3(a.nblk_w + nb), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_apply_delta(const ApplyArgs& a, hipStream_t st) {
+    const long long n = (long long)a.n_vis * a.n_hid + a.n_hid + a.n_vis;
+    hipLaunchKernelGGL(k_apply_delta, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_free_energy_finish(const FinishArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_free_energy_finish, dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace kurbm

@@ -1,0 +1,226 @@
+"""Device-side state of one RBM and the ctypes calls that drive the HIP kernels.
+
+PyTorch is used for exactly three things here: owning device memory (``torch.zeros`` /
+``data_ptr()``), naming the current HIP stream, and host<->device copies.  All arithmetic
+of the contrastive-divergence path happens inside ``libkurbm.so``.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import (ACT_LINEAR, ACT_RELU, ACT_SIGMOID, NOISE_BERNOULLI, NOISE_GAUSSIAN, NOISE_NONE,
+                    WHICH_ALL, CdOpts, Context, Params, Rng, check)
+
+MODE_VISIBLE_BERNOULLI = 0
+MODE_VISIBLE_GAUSSIAN = 1
+MODE_COMPLEX = 2
+
+# sampling-site ids of the RNG contract (include/kurbm.h; CPU statement: oracle/rbm_oracle.py)
+CHAIN_STRIDE = 64
+STREAM_TRANSFORM = 0x100
+STREAM_INV_TRANSFORM = 0x101
+CHAIN_W, CHAIN_BH, CHAIN_BV, CHAIN_SCORE = 0, 1, 2, 3
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def resolve_device(device=None):
+    """The gfx950 device this process drives.  No GPU -> loud failure (no CPU path exists)."""
+    if not torch.cuda.is_available():
+        raise _lib.KurbmError(
+            "no ROCm device visible: keras_unsupervised_amd runs its RBM/DBN path on MI355X (gfx950) "
+            "HIP kernels only and has no CPU fallback")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.KurbmError("device must be a ROCm ('cuda') device, got %s" % device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+class DeviceMatrix:
+    """Row-major fp32 [rows, ld] matrix on the device, ld % 4 == 0, padding zero."""
+
+    __slots__ = ("t", "rows", "cols", "ld")
+
+    def __init__(self, t, rows, cols, ld):
+        self.t, self.rows, self.cols, self.ld = t, rows, cols, ld
+
+    @classmethod
+    def zeros(cls, rows, cols, device):
+        ld = round_up(cols, 4)
+        return cls(torch.zeros((max(rows, 1), ld), dtype=torch.float32, device=device), rows, cols, ld)
+
+    @classmethod
+    def from_host(cls, x, device):
+        """Upload a numpy / torch [rows, cols] array (any float dtype) as fp32."""
+        if isinstance(x, torch.Tensor):
+            src = x.detach().to(dtype=torch.float32)
+        else:
+            src = torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32))
+        if src.dim() != 2:
+            raise ValueError("expected a 2-d array, got shape %s" % (tuple(src.shape),))
+        rows, cols = src.shape
+        ld = round_up(cols, 4)
+        if isinstance(x, torch.Tensor) and src.is_cuda and ld == cols and src.is_contiguous() \
+                and src.data_ptr() % 16 == 0 and src.device == device:
+            return cls(src, rows, cols, ld)  # already in the device layout: no copy
+        m = cls.zeros(rows, cols, device)
+        m.t[:rows, :cols].copy_(src, non_blocking=False)
+        return m
+
+    def ptr(self, row=0):
+        return self.t.data_ptr() + row * self.ld * 4
+
+    def to_numpy(self):
+        return self.t[: self.rows, : self.cols].contiguous().cpu().numpy()
+
+    def view(self):
+        """[rows, cols] torch view (device)."""
+        return self.t[: self.rows, : self.cols]
+
+
+class DeviceRBM:
+    """W, b_h, b_v on one device + scratch, and one method per C-ABI entry point."""
+
+    def __init__(self, W, b_h, b_v, device=None):
+        self.device = resolve_device(device)
+        self.ctx = Context.get(self.device.index)
+        self.lib = self.ctx.lib
+        W = np.asarray(W, dtype=np.float32)
+        self.n_vis, self.n_hid = W.shape
+        with torch.cuda.device(self.device):
+            self.W = DeviceMatrix.from_host(W, self.device)
+            if self.W.t.data_ptr() == 0:
+                raise _lib.KurbmError("device allocation failed")
+            self.b_h = torch.from_numpy(np.ascontiguousarray(b_h, dtype=np.float32)).to(self.device)
+            self.b_v = torch.from_numpy(np.ascontiguousarray(b_v, dtype=np.float32)).to(self.device)
+        assert self.b_h.numel() == self.n_hid and self.b_v.numel() == self.n_vis
+        self.params = Params(self.n_vis, self.n_hid, self.W.ld, 0, self.W.t.data_ptr(),
+                             self.b_h.data_ptr(), self.b_v.data_ptr())
+        self._ws = None
+        self._ws_rows = 0
+        self.delta = None  # packed [V*H | H | V] sums, allocated on first use
+
+    # -- plumbing -------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, rows, k=1):
+        if self._ws is None or rows > self._ws_rows:
+            n = self.lib.kurbm_workspace_bytes(self.ctx.handle, rows, self.n_vis, self.n_hid, k)
+            if n == 0:
+                raise _lib.KurbmError("kurbm_workspace_bytes failed")
+            self._ws = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self._ws_rows = rows
+        return self._ws
+
+    def delta_buffer(self):
+        if self.delta is None:
+            n = self.n_vis * self.n_hid + self.n_hid + self.n_vis
+            self.delta = torch.zeros(n, dtype=torch.float32, device=self.device)
+        return self.delta
+
+    def get_weights(self):
+        return self.W.to_numpy(), self.b_h.cpu().numpy(), self.b_v.cpu().numpy()
+
+    def set_weights(self, W=None, b_h=None, b_v=None):
+        if W is not None:
+            W = np.asarray(W, dtype=np.float32)
+            assert W.shape == (self.n_vis, self.n_hid)
+            self.W.t[:, : self.n_hid].copy_(torch.from_numpy(np.ascontiguousarray(W)))
+        if b_h is not None:
+            self.b_h.copy_(torch.from_numpy(np.ascontiguousarray(b_h, dtype=np.float32)))
+        if b_v is not None:
+            self.b_v.copy_(torch.from_numpy(np.ascontiguousarray(b_v, dtype=np.float32)))
+
+    # -- kernels --------------------------------------------------------------------
+    def half_step(self, direction, x, rows, row_start, act, noise, seed, stream_id, step, row0=0,
+                  want_sample=True, want_prob=False, want_u=False):
+        """One fused half step over rows [row_start, row_start+rows) of DeviceMatrix x.
+
+        direction 'vh': x is [*, n_vis] -> outputs [rows, n_hid];  'hv': the converse.
+        Returns dict of DeviceMatrix for the requested outputs.
+        """
+        n_out = self.n_hid if direction == "vh" else self.n_vis
+        n_in = self.n_vis if direction == "vh" else self.n_hid
+        if x.cols != n_in:
+            raise ValueError("input has %d columns, expected %d" % (x.cols, n_in))
+        out = {}
+        with torch.cuda.device(self.device):
+            for key, want in (("sample", want_sample), ("prob", want_prob), ("u", want_u)):
+                out[key] = DeviceMatrix.zeros(rows, n_out, self.device) if want else None
+            rng = Rng(int(seed), int(row0), int(stream_id) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF)
+            fn = self.lib.kurbm_half_step_vh_dbg if direction == "vh" else self.lib.kurbm_half_step_hv_dbg
+            ld_out = round_up(n_out, 4)
+            check(fn(self.ctx.handle, C.byref(self.params), x.ptr(row_start), rows, x.ld, act, noise,
+                     C.byref(rng), out["sample"].ptr() if want_sample else None,
+                     out["prob"].ptr() if want_prob else None, out["u"].ptr() if want_u else None,
+                     ld_out, self._stream()))
+        return out
+
+    def cd_step(self, v, rows, row_start, lr, seed, step, k=1, mode=MODE_VISIBLE_BERNOULLI, chain=0,
+                which=WHICH_ALL, apply=True, emit_delta=False, v_chain=None, row0=0, v_chain_row=0):
+        """One CD-k update on rows [row_start, row_start+rows) of DeviceMatrix v."""
+        with torch.cuda.device(self.device):
+            ws = self.workspace(rows, k)
+            opts = CdOpts(int(k), int(mode), float(lr), 1 if apply else 0,
+                          self.delta_buffer().data_ptr() if emit_delta else None,
+                          v_chain.ptr(v_chain_row) if v_chain is not None else None,
+                          int(seed), int(row0), int(step) & 0xFFFFFFFF, int(chain))
+            check(self.lib.kurbm_cd_step(self.ctx.handle, C.byref(self.params), v.ptr(row_start), rows, v.ld,
+                                         C.byref(opts), int(which), ws.data_ptr(), ws.numel(), self._stream()))
+
+    def apply_delta(self, lr, which=WHICH_ALL, delta=None):
+        delta = self.delta_buffer() if delta is None else delta
+        with torch.cuda.device(self.device):
+            check(self.lib.kurbm_apply_delta(self.ctx.handle, C.byref(self.params), delta.data_ptr(), float(lr),
+                                             int(which), self._stream()))
+
+    def free_energy(self, v, rows, row_start=0):
+        with torch.cuda.device(self.device):
+            ws = self.workspace(rows)
+            F = torch.empty(rows, dtype=torch.float32, device=self.device)
+            check(self.lib.kurbm_free_energy(self.ctx.handle, C.byref(self.params), v.ptr(row_start), rows, v.ld,
+                                             F.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        return F
+
+    def philox_uniform(self, rows, cols, seed, stream_id, step, row0=0):
+        with torch.cuda.device(self.device):
+            out = DeviceMatrix.zeros(rows, cols, self.device)
+            rng = Rng(int(seed), int(row0), int(stream_id) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF)
+            check(self.lib.kurbm_philox_uniform(self.ctx.handle, out.ptr(), rows, cols, out.ld, C.byref(rng),
+                                                self._stream()))
+        return out
+
+    def outer_delta(self, v_pos, h_pos, v_neg, h_neg, rows):
+        """dW = v_pos^T.h_pos - v_neg^T.h_neg as a dense [n_vis, n_hid] tensor (test / bench hook)."""
+        with torch.cuda.device(self.device):
+            ws = self.workspace(rows)
+            out = torch.empty((self.n_vis, self.n_hid), dtype=torch.float32, device=self.device)
+            check(self.lib.kurbm_outer_delta(self.ctx.handle, v_pos.ptr(), h_pos.ptr(), v_neg.ptr(), h_neg.ptr(),
+                                             rows, self.n_vis, self.n_hid, v_pos.ld, h_pos.ld, out.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), self._stream()))
+        return out
+
+
+def hidden_site(mode):
+    """(activation, noise) of the v->h sampling site for an RBM mode (rbm.py:46-47 vs :58-59)."""
+    return (ACT_RELU if mode == MODE_VISIBLE_GAUSSIAN else ACT_SIGMOID), NOISE_BERNOULLI
+
+
+def visible_site(mode):
+    """(activation, noise) of the h->v sampling site (rbm.py:52-53 vs :64-66)."""
+    if mode == MODE_VISIBLE_GAUSSIAN:
+        return ACT_LINEAR, NOISE_GAUSSIAN
+    return ACT_SIGMOID, NOISE_BERNOULLI
+
+
+__all__ = ["DeviceRBM", "DeviceMatrix", "resolve_device", "hidden_site", "visible_site", "round_up",
+           "MODE_VISIBLE_BERNOULLI", "MODE_VISIBLE_GAUSSIAN", "MODE_COMPLEX", "NOISE_NONE"]

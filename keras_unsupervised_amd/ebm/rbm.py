@@ -1,0 +1,295 @@
+"""RBM with the class surface of the reference ``ku.ebm.RBM`` (reference ku/ebm/rbm.py:19-242),
+driven by hand-written gfx950 HIP kernels through the C ABI of ``include/kurbm.h``.
+
+What is kept verbatim from the reference: the constructor signature
+``RBM(hps, output_dim, name=None, mode=MODE_VISIBLE_GAUSSIAN, **kwargs)`` (rbm.py:22), the hps
+keys ``batch_size`` / ``epochs`` / ``lr`` (rbm.py:46,113,128), the methods ``build`` / ``call`` /
+``transform`` / ``inv_transform`` / ``cal_free_energy`` / ``fit`` / ``compute_output_shape`` /
+``get_config``, the attributes ``rbm_weight`` / ``hidden_bias`` / ``visible_bias``, the batch order
+of ``fit`` (contiguous, unshuffled, remainder last: rbm.py:110-111, :211, :218), the update rules
+(sums over the batch scaled by lr only: rbm.py:125-134) and the per-step score print
+(rbm.py:225-234).  The TensorFlow graph machinery (placeholders, K.function) is gone.
+
+Where the reference cannot run as written, the minimal repairs of SURVEY.md 8(a) apply (uniform
+shape follows the probabilities, remainder-batch shape, list returns of K.function, ...).
+
+Extensions, all off by default or reference-preserving: ``update_mode='fused'`` (one Gibbs chain
+feeds all three updates; ``'reference_sequential'`` replays the reference's three chains),
+``cd_k``, ``persistent`` chains, ``seed``, data-parallel training when torch.distributed is
+initialised, ``verbose=0`` to skip the score passes.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from . import dp
+from .engine import (CHAIN_BH, CHAIN_BV, CHAIN_SCORE, CHAIN_STRIDE, CHAIN_W, MODE_COMPLEX,
+                     MODE_VISIBLE_BERNOULLI, MODE_VISIBLE_GAUSSIAN, STREAM_INV_TRANSFORM, STREAM_TRANSFORM,
+                     DeviceMatrix, DeviceRBM, hidden_site, resolve_device, visible_site)
+
+_UPDATE_MODES = ("fused", "reference_sequential")
+
+
+def _unwrap(x):
+    """K.function takes and returns 1-element lists (rbm.py:89, :211, :233): accept both forms."""
+    if isinstance(x, (list, tuple)):
+        if len(x) != 1:
+            raise ValueError("expected an array or a 1-element list of arrays")
+        return x[0]
+    return x
+
+
+class RBM(object):
+    """Restricted Boltzmann machine trained by contrastive divergence on MI355X."""
+
+    def __init__(self, hps, output_dim, name=None, mode=MODE_VISIBLE_GAUSSIAN, **kwargs):
+        self.hps = hps
+        self.output_dim = int(output_dim)
+        self.name = name
+        self.mode = mode
+        if mode not in (MODE_VISIBLE_BERNOULLI, MODE_VISIBLE_GAUSSIAN):
+            # MODE_COMPLEX is a TODO in the reference too (rbm.py:16, :68-70)
+            raise ValueError("unsupported RBM mode %r" % (mode,))
+        opt = lambda key, default: kwargs.pop(key, hps.get(key, default) if hasattr(hps, "get") else default)
+        self.seed = int(opt("seed", 0))
+        self.update_mode = opt("update_mode", "fused")
+        if self.update_mode not in _UPDATE_MODES:
+            raise ValueError("update_mode must be one of %s" % (_UPDATE_MODES,))
+        self.cd_k = int(opt("cd_k", 1))
+        self.persistent = bool(opt("persistent", False))
+        self.list_returns = bool(kwargs.pop("ku_compat_list_returns", True))
+        self._device_arg = kwargs.pop("device", None)
+        self._init_weights = kwargs.pop("weights", None)
+        self._kwargs = kwargs          # remaining Keras Layer kwargs (dtype, trainable, ...) are kept for get_config
+        self.built = False
+        self.input_shape = None
+        self.output_shape = None
+        self._dev = None               # DeviceRBM
+        self._update_count = 0         # `step` of the RNG contract for fit()
+        self._call_count = 0           # `step` of the RNG contract for transform / inv_transform / call
+        self._v_chain = None           # persistent fantasy particles
+        self.last_scores = []
+
+    # ------------------------------------------------------------------ build ----------
+    def build(self, input_shape):
+        """Create W ~ U(-0.05, 0.05) [n_vis, n_hid], b_h, b_v on the device (rbm.py:29-40)."""
+        n_vis = int(input_shape[1])
+        if self._init_weights is not None:
+            W, b_h, b_v = self._init_weights
+        else:
+            g = np.random.default_rng(self.seed)
+            W = g.uniform(-0.05, 0.05, size=(n_vis, self.output_dim)).astype(np.float32)
+            b_h = g.uniform(-0.05, 0.05, size=(self.output_dim,)).astype(np.float32)
+            b_v = g.uniform(-0.05, 0.05, size=(n_vis,)).astype(np.float32)
+        W = np.asarray(W, dtype=np.float32)
+        if W.shape != (n_vis, self.output_dim):
+            raise ValueError("weights have shape %s, expected %s" % (W.shape, (n_vis, self.output_dim)))
+        self._dev = DeviceRBM(W, b_h, b_v, resolve_device(self._device_arg))
+        self.input_shape = (None, n_vis)
+        self.output_shape = (None, self.output_dim)
+        self.built = True
+
+    def _ensure_built(self, n_cols):
+        if not self.built:
+            self.build((None, n_cols))
+
+    # ------------------------------------------------------------------ variables ------
+    @property
+    def rbm_weight(self):
+        return self._dev.get_weights()[0]
+
+    @rbm_weight.setter
+    def rbm_weight(self, W):
+        self._dev.set_weights(W=W)
+
+    @property
+    def hidden_bias(self):
+        return self._dev.get_weights()[1]
+
+    @hidden_bias.setter
+    def hidden_bias(self, b):
+        self._dev.set_weights(b_h=b)
+
+    @property
+    def visible_bias(self):
+        return self._dev.get_weights()[2]
+
+    @visible_bias.setter
+    def visible_bias(self, b):
+        self._dev.set_weights(b_v=b)
+
+    def get_weights(self):
+        """[rbm_weight, rbm_hidden_bias, rbm_visible_bias] -- unlike the reference, the visible bias
+        is included (there it is a bare K.variable and is silently dropped: rbm.py:38-40)."""
+        return list(self._dev.get_weights())
+
+    def set_weights(self, weights):
+        W, b_h = weights[0], weights[1]
+        b_v = weights[2] if len(weights) > 2 else None
+        self._dev.set_weights(W, b_h, b_v)
+
+    # ------------------------------------------------------------------ forward passes --
+    def _as_device(self, x):
+        x = _unwrap(x)
+        if isinstance(x, DeviceMatrix):
+            return x, "device"
+        n_cols = x.shape[1]
+        kind = "torch" if isinstance(x, torch.Tensor) else "numpy"
+        dev = self._dev.device if self._dev is not None else resolve_device(self._device_arg)
+        with torch.cuda.device(dev):
+            return DeviceMatrix.from_host(x, dev), kind
+
+    def _ret(self, m, kind, as_list):
+        if kind == "device":
+            out = m
+        elif kind == "torch":
+            out = m.view()
+        else:
+            out = m.to_numpy()
+        return [out] if as_list else out
+
+    def _sample_hidden(self, x):
+        act, noise = hidden_site(self.mode)
+        out = self._dev.half_step("vh", x, x.rows, 0, act, noise, self.seed, STREAM_TRANSFORM, self._call_count)
+        self._call_count += 1
+        return out["sample"]
+
+    def _sample_visible(self, h):
+        act, noise = visible_site(self.mode)
+        out = self._dev.half_step("hv", h, h.rows, 0, act, noise, self.seed, STREAM_INV_TRANSFORM, self._call_count)
+        self._call_count += 1
+        return out["sample"]
+
+    def transform(self, v):
+        """Sampled hidden states of v (transform_func, rbm.py:88-89 -> :46-48 / :58-60)."""
+        n_cols = _unwrap(v).cols if isinstance(_unwrap(v), DeviceMatrix) else _unwrap(v).shape[1]
+        self._ensure_built(n_cols)
+        x, kind = self._as_device(v)
+        return self._ret(self._sample_hidden(x), kind, self.list_returns and kind != "device")
+
+    def inv_transform(self, h):
+        """Sampled visible states of h (inv_transform_func, rbm.py:91-92 -> :52-54 / :64-67)."""
+        if not self.built:
+            raise ValueError("inv_transform needs a built RBM (call build / fit / transform first)")
+        x, kind = self._as_device(h)
+        return self._ret(self._sample_visible(x), kind, self.list_returns and kind != "device")
+
+    def call(self, x):
+        """The layer's forward pass: stochastic hidden features (rbm.py:80-86)."""
+        n_cols = _unwrap(x).shape[1]
+        self._ensure_built(n_cols)
+        xd, kind = self._as_device(x)
+        return self._ret(self._sample_hidden(xd), kind, False)
+
+    __call__ = call
+
+    def cal_free_energy(self, v):
+        """F(v) = -(v.b_v + sum_j softplus((v.W + b_h)_j))   (free_energy_func, rbm.py:97-98 -> :73-76)."""
+        n_cols = _unwrap(v).cols if isinstance(_unwrap(v), DeviceMatrix) else _unwrap(v).shape[1]
+        self._ensure_built(n_cols)
+        x, kind = self._as_device(v)
+        F = self._dev.free_energy(x, x.rows)
+        if kind in ("device", "torch"):
+            return [F] if (self.list_returns and kind != "device") else F
+        F = F.cpu().numpy()
+        return [F] if self.list_returns else F
+
+    def compute_output_shape(self, input_shape):
+        return (input_shape[0], self.output_dim)          # rbm.py:94-95
+
+    # ------------------------------------------------------------------ training --------
+    def _score(self, Vd, lo, rows, step):
+        """mean |F(v) - F(v')| with v' a fresh one-step reconstruction (rbm.py:225-233)."""
+        d = self._dev
+        fe = d.free_energy(Vd, rows, lo)
+        act_h, noise_h = hidden_site(self.mode)
+        act_v, noise_v = visible_site(self.mode)
+        base = CHAIN_SCORE * CHAIN_STRIDE
+        h = d.half_step("vh", Vd, rows, lo, act_h, noise_h, self.seed, base + 0, step)["sample"]
+        v1 = d.half_step("hv", h, rows, 0, act_v, noise_v, self.seed, base + 1, step)["sample"]
+        fe_p = d.free_energy(v1, rows, 0)
+        return float((fe - fe_p).abs().mean().item())
+
+    def fit(self, V, verbose=1):
+        """Train the RBM on V [N, n_vis] by CD-k (rbm.py:100-234).
+
+        V: numpy array, torch tensor (host or device) -- uploaded once and kept resident.
+        verbose: 1 prints the epoch counter and the per-step score as the reference does
+                 (rbm.py:114-115, :234); 0 prints nothing and skips the three score passes.
+        Returns None.
+        """
+        V = _unwrap(V)
+        n_cols = V.cols if isinstance(V, DeviceMatrix) else V.shape[1]
+        self._ensure_built(n_cols)
+        Vd, _ = self._as_device(V)
+        if Vd.cols != self._dev.n_vis:
+            raise ValueError("V has %d columns, the RBM has %d visible units" % (Vd.cols, self._dev.n_vis))
+        bs = int(self.hps["batch_size"])
+        lr = float(self.hps["lr"])
+        n = Vd.rows
+        num_step = n // bs if n % bs == 0 else n // bs + 1                     # rbm.py:110-111
+        rank, world = dp.world()
+        d = self._dev
+        self.last_scores = []
+        if self.persistent and self._v_chain is None:
+            # fantasy particles start at the first batch of the data
+            self._v_chain = DeviceMatrix.zeros(bs, d.n_vis, d.device)
+            first = min(bs, n)
+            self._v_chain.t[:first].copy_(Vd.t[:first])
+
+        for epoch in range(int(self.hps["epochs"])):                              # rbm.py:113
+            if verbose == 1:
+                print(epoch + 1, "/", self.hps["epochs"], " epochs", end="\r")   # rbm.py:115
+            for i in range(num_step):                                            # rbm.py:163
+                lo, hi = i * bs, min((i + 1) * bs, n)                            # rbm.py:211 / :218
+                rows = hi - lo
+                step = self._update_count
+                if world == 1:
+                    self._update_local(Vd, lo, rows, lr, step)
+                else:
+                    self._update_data_parallel(Vd, lo, rows, lr, step, rank, world)
+                self._update_count += 1
+                if verbose == 1:
+                    score = self._score(Vd, lo, rows, step)
+                    self.last_scores.append(score)
+                    print("\n{0:d}/{1:d}, score: {2:f}".format(i + 1, num_step, score))   # rbm.py:234
+        return None
+
+    def _update_local(self, Vd, lo, rows, lr, step):
+        d = self._dev
+        if self.update_mode == "fused":
+            d.cd_step(Vd, rows, lo, lr, self.seed, step, k=self.cd_k, mode=self.mode, chain=CHAIN_W,
+                      v_chain=self._v_chain if self.persistent else None)
+        else:
+            # the reference's three K.function calls: each its own chain, each seeing the variables
+            # the previous call already updated (rbm.py:214-216)
+            for chain, which in ((CHAIN_W, _lib.WHICH_W), (CHAIN_BH, _lib.WHICH_BH), (CHAIN_BV, _lib.WHICH_BV)):
+                d.cd_step(Vd, rows, lo, lr, self.seed, step, k=1, mode=self.mode, chain=chain, which=which)
+
+    def _update_data_parallel(self, Vd, lo, rows, lr, step, rank, world):
+        """Each rank: chain on its rows -> packed sums -> one all-reduce -> identical apply."""
+        if self.update_mode != "fused":
+            raise ValueError("data-parallel training supports update_mode='fused' only")
+        d = self._dev
+        s_lo, s_hi = dp.shard_rows(rows, world, rank)
+        delta = d.delta_buffer()
+        if s_hi > s_lo:
+            d.cd_step(Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,
+                      chain=CHAIN_W, apply=False, emit_delta=True, row0=s_lo,
+                      v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo)
+        else:
+            delta.zero_()
+        dp.allreduce_sum_(delta)
+        d.apply_delta(lr)
+
+    # ------------------------------------------------------------------ config ----------
+    def get_config(self):
+        """hps, output_dim, name as in rbm.py:236-242, plus `mode` (dropped by the reference) and the
+        extension knobs, so that RBM(**config) rebuilds the same layer."""
+        config = {"hps": self.hps, "output_dim": self.output_dim, "name": self.name, "mode": self.mode,
+                  "seed": self.seed, "update_mode": self.update_mode, "cd_k": self.cd_k,
+                  "persistent": self.persistent}
+        return dict(list(self._kwargs.items()) + list(config.items()))
+
+
+__all__ = ["RBM", "MODE_VISIBLE_BERNOULLI", "MODE_VISIBLE_GAUSSIAN", "MODE_COMPLEX"]

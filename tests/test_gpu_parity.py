@@ -1,0 +1,366 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Bars (north_star): uniforms bit-exact; probabilities / weight updates within 1e-4 (relative to
+max(1, |ref|) for batch sums); Bernoulli samples equal to (u < p_gpu) exactly, and equal to the
+oracle's samples except where |u - p| < 1e-5 (the GEMM rounding band).  Downstream stages are
+checked teacher-forced: the oracle is fed the GPU's own samples of the previous stage.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+from oracle import rbm_oracle as O
+from oracle.make_golden import synthetic_binary, synthetic_params, synthetic_real
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # north_star tolerance, fp32
+FLIP_BAND = 1e-5    # |u - p| below which a sample may legitimately differ
+
+
+def _engine(W, b_h, b_v, device):
+    from keras_unsupervised_amd.ebm.engine import DeviceRBM
+    return DeviceRBM(W, b_h, b_v, device)
+
+
+def _dm(x, device):
+    from keras_unsupervised_amd.ebm.engine import DeviceMatrix
+    return DeviceMatrix.from_host(x, device)
+
+
+def rel_err(a, ref):
+    return np.max(np.abs(a.astype(np.float64) - ref.astype(np.float64)) / np.maximum(1.0, np.abs(ref.astype(np.float64))))
+
+
+def check_half_step(out, p_ref, u_ref, s_ref):
+    """Shared assertions for one Bernoulli half step."""
+    p, u, s = out["prob"].to_numpy(), out["u"].to_numpy(), out["sample"].to_numpy()
+    assert np.array_equal(u.view(np.uint32), u_ref.view(np.uint32)), "uniforms must be bit-exact"
+    assert np.max(np.abs(p - p_ref)) <= TOL
+    assert np.array_equal(s, (u < p).astype(np.float32)), "sample must be exactly (u < p) of the GPU's own p"
+    diff = s != s_ref
+    if diff.any():
+        assert np.all(np.abs(u_ref[diff] - p_ref[diff]) < FLIP_BAND), "sample differs outside the rounding band"
+    return int(diff.sum())
+
+
+# ---------------------------------------------------------------------------------------
+def test_philox_uniform_bit_exact(gpu_device, golden_dir):
+    W, b_h, b_v = synthetic_params(8, 8, 1)
+    e = _engine(W, b_h, b_v, gpu_device)
+    g = np.load(os.path.join(golden_dir, "philox.npz"))
+    for s in range(4):
+        u = e.philox_uniform(8, 8, 0, s, 0).to_numpy()
+        assert np.array_equal(u.view(np.uint32), g["uniforms"][s].view(np.uint32))
+    u = e.philox_uniform(8, 8, 42, 3, 7, row0=8).to_numpy()
+    assert np.array_equal(u.view(np.uint32), g["uniforms_seed42_row0_8"].view(np.uint32))
+    # ragged shape, 64-bit seed, large row offset: against the live oracle
+    seed = (0xDEADBEEF << 32) | 0x12345678
+    u = e.philox_uniform(37, 101, seed, 0x80000005, 0xFFFFFFF0, row0=(1 << 33) + 4).to_numpy()
+    ref = philox.uniform(37, 101, seed, 0x80000005, 0xFFFFFFF0, row0=(1 << 33) + 4)
+    assert np.array_equal(u.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_half_steps_config1_golden(gpu_device, golden_dir, B):
+    """784 x 256 (config 1 shape): both half steps against the golden fixture and the live oracle."""
+    W, b_h, b_v = synthetic_params(784, 256, seed=11)
+    v = synthetic_binary(B, 784, seed=12)
+    e = _engine(W, b_h, b_v, gpu_device)
+    g = np.load(os.path.join(golden_dir, "half_step_B%d.npz" % B))
+    sub = int(g["row_stride"])
+    vd = _dm(v, gpu_device)
+    out = e.half_step("vh", vd, B, 0, 0, 1, 42, 0, 5, want_prob=True, want_u=True)
+    rng = O.Rng(42, 5)
+    p_ref, u_ref, h_ref = O.sample_hidden(v, W, b_h, rng, 0)
+    check_half_step(out, p_ref, u_ref, h_ref)
+    assert np.array_equal(out["u"].to_numpy()[::sub].view(np.uint32), g["u_h"].view(np.uint32))
+    assert np.max(np.abs(out["prob"].to_numpy()[::sub] - g["p_h"])) <= TOL
+    h_gold = np.unpackbits(g["h"], axis=1)[:, :256].astype(np.float32)
+    assert np.array_equal(out["sample"].to_numpy(), h_gold)
+    # h -> v, teacher-forced with the GPU's h
+    h = out["sample"].to_numpy()
+    out2 = e.half_step("hv", out["sample"], B, 0, 0, 1, 42, 1, 5, want_prob=True, want_u=True)
+    p_ref, u_ref, v_ref = O.sample_visible(h, W, b_v, rng, 1)
+    check_half_step(out2, p_ref, u_ref, v_ref)
+    v_gold = np.unpackbits(g["v1"], axis=1)[:, :784].astype(np.float32)
+    assert np.array_equal(out2["sample"].to_numpy(), v_gold)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 3), (3, 17, 9), (130, 100, 70), (257, 113, 129), (100, 784, 128),
+                                   (260, 224, 240)])
+def test_half_steps_ragged_shapes(gpu_device, shape):
+    """Edge shapes: single row, sizes that are not multiples of the tiles or of 4, real-valued input."""
+    B, nv, nh = shape
+    W, b_h, b_v = synthetic_params(nv, nh, seed=100 + B)
+    v = synthetic_real(B, nv, seed=200 + B)
+    e = _engine(W, b_h, b_v, gpu_device)
+    rng = O.Rng(9, 2, row0=8)
+    out = e.half_step("vh", _dm(v, gpu_device), B, 0, 0, 1, 9, 4, 2, row0=8, want_prob=True, want_u=True)
+    p_ref, u_ref, h_ref = O.sample_hidden(v, W, b_h, rng, 4)
+    check_half_step(out, p_ref, u_ref, h_ref)
+    h = synthetic_real(B, nh, seed=300 + B)
+    out = e.half_step("hv", _dm(h, gpu_device), B, 0, 0, 1, 9, 5, 2, row0=8, want_prob=True, want_u=True)
+    p_ref, u_ref, v_ref = O.sample_visible(h, W, b_v, rng, 5)
+    check_half_step(out, p_ref, u_ref, v_ref)
+    # padding columns of the outputs stay untouched (zero)
+    t = out["sample"].t
+    if t.shape[1] > nv:
+        assert float(t[:, nv:].abs().max().item()) == 0.0
+
+
+def test_half_step_row_window_and_prob_only(gpu_device):
+    """A batch is a row window of the resident data matrix; NOISE_NONE writes probabilities only."""
+    W, b_h, b_v = synthetic_params(96, 80, seed=5)
+    V = synthetic_real(50, 96, seed=6)
+    e = _engine(W, b_h, b_v, gpu_device)
+    out = e.half_step("vh", _dm(V, gpu_device), 20, 12, 0, 0, 0, 0, 0, want_sample=False, want_prob=True)
+    ref = O.hidden_prob(V[12:32], W, b_h)
+    assert np.max(np.abs(out["prob"].to_numpy() - ref)) <= TOL
+
+
+def test_gaussian_mode_half_steps(gpu_device):
+    """relu-threshold hidden units and N(loc, 1) visible units (rbm.py:57-67)."""
+    W, b_h, b_v = synthetic_params(72, 40, seed=8)
+    W = W * 20.0  # spread the pre-activations so relu(x) covers (0, 1) and beyond
+    v = synthetic_real(33, 72, seed=9)
+    e = _engine(W, b_h, b_v, gpu_device)
+    rng = O.Rng(3, 1)
+    out = e.half_step("vh", _dm(v, gpu_device), 33, 0, 1, 1, 3, 0, 1, want_prob=True, want_u=True)
+    p_ref, u_ref, h_ref = O.sample_hidden(v, W, b_h, rng, 0, O.MODE_VISIBLE_GAUSSIAN)
+    check_half_step(out, p_ref, u_ref, h_ref)
+    h = out["sample"].to_numpy()
+    out = e.half_step("hv", out["sample"], 33, 0, 2, 2, 3, 1, 1, want_prob=True)
+    loc, z, v1 = O.sample_visible(h, W, b_v, rng, 1, O.MODE_VISIBLE_GAUSSIAN)
+    assert np.max(np.abs(out["prob"].to_numpy() - loc)) <= TOL
+    assert np.max(np.abs(out["sample"].to_numpy() - v1)) <= 5e-4   # Box-Muller in fp32: log/cos rounding
+    assert abs(float(z.mean())) < 0.1
+
+
+def test_free_energy(gpu_device, golden_dir):
+    nv, nh = 64, 48
+    W, b_h, b_v = synthetic_params(nv, nh, seed=51)
+    v = synthetic_real(6, nv, seed=52)
+    v[5] *= 4000.0
+    W2 = W.copy()
+    W2[:, 0] = 0.05
+    e = _engine(W2, b_h, b_v, gpu_device)
+    F = e.free_energy(_dm(v, gpu_device), 6).cpu().numpy()
+    g = np.load(os.path.join(golden_dir, "free_energy.npz"))
+    assert np.all(np.isfinite(F))
+    assert rel_err(F, g["F_stable"]) <= TOL
+    assert np.isinf(g["F_naive"][5])            # the reference's literal softplus overflows here
+    # a bigger ragged case against the float64 oracle
+    W, b_h, b_v = synthetic_params(300, 200, seed=53)
+    v = synthetic_real(150, 300, seed=54)
+    F = _engine(W, b_h, b_v, gpu_device).free_energy(_dm(v, gpu_device), 150).cpu().numpy()
+    ref = O.free_energy(v.astype(np.float64), W.astype(np.float64), b_h.astype(np.float64), b_v.astype(np.float64))
+    assert rel_err(F, ref) <= TOL
+
+
+# ---------------------------------------------------------------------------------------
+def _gpu_cd_delta(e, vd, rows, lr, seed, step, **kw):
+    e.cd_step(vd, rows, 0, lr, seed, step, apply=False, emit_delta=True, **kw)
+    torch.cuda.synchronize()
+    return e.delta_buffer().cpu().numpy().copy()
+
+
+def _split(delta, nv, nh):
+    return delta[: nv * nh].reshape(nv, nh), delta[nv * nh: nv * nh + nh], delta[nv * nh + nh:]
+
+
+def test_cd_step_small_golden(gpu_device, golden_dir):
+    """One fused CD-1 update, 64 x 48, B = 24: delta and updated parameters vs golden + oracle."""
+    nv, nh, B = 64, 48, 24
+    W, b_h, b_v = synthetic_params(nv, nh, seed=21)
+    v = synthetic_binary(B, nv, seed=22, p=0.3)
+    g = np.load(os.path.join(golden_dir, "cd_step_small.npz"))
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(v, gpu_device)
+    dW, dbh, dbv = _split(_gpu_cd_delta(e, vd, B, 0.01, 7, 3), nv, nh)
+    assert rel_err(dW, g["dW"]) <= TOL
+    assert rel_err(dbh, g["dbh"]) <= TOL
+    assert np.array_equal(dbv, g["dbv"])          # integer-valued: exact
+    # in-place apply
+    e.cd_step(vd, B, 0, 0.01, 7, 3)
+    Wn, bhn, bvn = e.get_weights()
+    assert np.max(np.abs(Wn - g["W_fused"])) <= TOL
+    assert np.max(np.abs(bhn - g["bh_fused"])) <= TOL
+    assert np.max(np.abs(bvn - g["bv_fused"])) <= TOL
+    # the reference's three sequential chains (rbm.py:214-216)
+    e2 = _engine(W, b_h, b_v, gpu_device)
+    for chain, which in ((0, 1), (1, 2), (2, 4)):
+        e2.cd_step(vd, B, 0, 0.01, 7, 3, chain=chain, which=which)
+    Wn, bhn, bvn = e2.get_weights()
+    assert np.max(np.abs(Wn - g["W_seq"])) <= TOL
+    assert np.max(np.abs(bhn - g["bh_seq"])) <= TOL
+    assert np.max(np.abs(bvn - g["bv_seq"])) <= TOL
+
+
+def test_cd_step_config1_golden(gpu_device, golden_dir):
+    W, b_h, b_v = synthetic_params(784, 256, seed=11)
+    v = synthetic_binary(64, 784, seed=12)
+    g = np.load(os.path.join(golden_dir, "cd_step_config1.npz"))
+    e = _engine(W, b_h, b_v, gpu_device)
+    dW, dbh, dbv = _split(_gpu_cd_delta(e, _dm(v, gpu_device), 64, 1e-3, 42, 0), 784, 256)
+    assert rel_err(dW[::49, ::16], g["dW_sub"]) <= TOL
+    assert abs(dW.astype(np.float64).sum() - float(g["dW_sum"])) <= TOL * float(g["dW_abs_sum"])
+    assert rel_err(dbh, g["dbh"]) <= TOL
+    assert np.array_equal(dbv, g["dbv"])
+
+
+@pytest.mark.parametrize("cfg", [dict(B=50, nv=70, nh=90, k=1), dict(B=133, nv=200, nh=120, k=3),
+                                 dict(B=64, nv=784, nh=256, k=1), dict(B=40, nv=48, nh=64, k=2, pcd=True),
+                                 dict(B=30, nv=52, nh=44, k=1, gauss=True)])
+def test_cd_step_vs_oracle(gpu_device, cfg):
+    """CD-k, persistent chains and Gaussian mode against the live oracle; the run is deterministic."""
+    B, nv, nh, k = cfg["B"], cfg["nv"], cfg["nh"], cfg["k"]
+    gauss = cfg.get("gauss", False)
+    mode = O.MODE_VISIBLE_GAUSSIAN if gauss else O.MODE_VISIBLE_BERNOULLI
+    W, b_h, b_v = synthetic_params(nv, nh, seed=60 + B)
+    v = synthetic_real(B, nv, seed=61 + B) if gauss else synthetic_binary(B, nv, seed=61 + B, p=0.3)
+    chain0 = synthetic_binary(B, nv, seed=62 + B, p=0.5) if cfg.get("pcd") else None
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(v, gpu_device)
+    cd = _dm(chain0, gpu_device) if chain0 is not None else None
+    d1 = _gpu_cd_delta(e, vd, B, 0.05, 77, 9, k=k, mode=mode, v_chain=cd)
+    _, _, _, ch, (dW_ref, dbh_ref, dbv_ref) = O.cd_step_fused(W, b_h, b_v, v, 0.05, 77, 9, k=k, mode=mode, v_chain=chain0)
+    dW, dbh, dbv = _split(d1, nv, nh)
+    tol = 5e-4 if gauss else TOL
+    assert rel_err(dW, dW_ref) <= tol
+    assert rel_err(dbh, dbh_ref) <= tol
+    assert rel_err(dbv, dbv_ref) <= tol
+    if cd is not None:   # the chain buffer now holds v_neg
+        assert np.array_equal(cd.to_numpy(), ch["v_neg"])
+        cd = _dm(chain0, gpu_device)
+    d2 = _gpu_cd_delta(e, vd, B, 0.05, 77, 9, k=k, mode=mode, v_chain=cd)
+    assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32)), "same inputs, same counters -> same bits"
+
+
+def test_full_size_step_properties(gpu_device):
+    """Config 2 (784 x 1024, B = 4096): stage-by-stage, teacher-forced, plus size-independent properties."""
+    B, nv, nh = 4096, 784, 1024
+    W, b_h, b_v = synthetic_params(nv, nh, seed=1)
+    v = synthetic_binary(B, nv, seed=1234)
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(v, gpu_device)
+    seed, step = 42, 17
+    rng = O.Rng(seed, step)
+    # stage 1: h_pos
+    o1 = e.half_step("vh", vd, B, 0, 0, 1, seed, 0, step, want_prob=True, want_u=True)
+    n_flip = check_half_step(o1, *O.sample_hidden(v, W, b_h, rng, 0))
+    h_pos = o1["sample"].to_numpy()
+    # stage 2: v_neg from the GPU's h_pos
+    o2 = e.half_step("hv", o1["sample"], B, 0, 0, 1, seed, 1, step, want_prob=True, want_u=True)
+    n_flip += check_half_step(o2, *O.sample_visible(h_pos, W, b_v, rng, 1))
+    v_neg = o2["sample"].to_numpy()
+    # stage 3: h_neg probabilities from the GPU's v_neg
+    o3 = e.half_step("vh", o2["sample"], B, 0, 0, 0, seed, 0, step, want_sample=False, want_prob=True)
+    h_neg = o3["prob"].to_numpy()
+    assert np.max(np.abs(h_neg - O.hidden_prob(v_neg, W, b_h))) <= TOL
+    assert n_flip < 64, "far more borderline samples than fp32 rounding explains"
+    # stage 4: statistics from the GPU's own states, float64 reference
+    dW = e.outer_delta(vd, o1["sample"], o2["sample"], o3["prob"], B).cpu().numpy()
+    ref = v.astype(np.float64).T @ h_pos.astype(np.float64) - v_neg.astype(np.float64).T @ h_neg.astype(np.float64)
+    assert rel_err(dW, ref) <= TOL
+    # the fused launch sequence reproduces exactly these stages
+    d = _gpu_cd_delta(e, vd, B, 1e-3, seed, step)
+    dW2, dbh, dbv = _split(d, nv, nh)
+    assert np.array_equal(dW2.view(np.uint32), dW.view(np.uint32))
+    assert np.array_equal(dbv, v.sum(0) - v_neg.sum(0))                       # integers: exact
+    assert rel_err(dbh, h_pos.astype(np.float64).sum(0) - h_neg.astype(np.float64).sum(0)) <= TOL
+    # linearity of the statistics in the batch: two half batches sum to the whole
+    e.cd_step(vd, B // 2, 0, 1e-3, seed, step, apply=False, emit_delta=True)
+    da = e.delta_buffer().cpu().numpy().copy()
+    e.cd_step(vd, B // 2, B // 2, 1e-3, seed, step, apply=False, emit_delta=True, row0=B // 2)
+    db = e.delta_buffer().cpu().numpy().copy()
+    assert rel_err(da + db, d) <= TOL
+    # apply: W_new - W_old == lr * dW
+    e.apply_delta(1e-3, delta=torch.from_numpy(d).to(gpu_device))
+    Wn = e.get_weights()[0]
+    assert np.max(np.abs((Wn - W) - 1e-3 * dW)) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------
+def test_rbm_fit_trajectory_golden(gpu_device, golden_dir, capsys):
+    """RBM.fit through the reference's class surface: N = 150, bs = 64 (remainder batch), both modes."""
+    from keras_unsupervised_amd.ebm import MODE_VISIBLE_BERNOULLI, RBM
+    nv, nh = 64, 48
+    W, b_h, b_v = synthetic_params(nv, nh, seed=31)
+    V = synthetic_binary(150, nv, seed=32, p=0.3)
+    g = np.load(os.path.join(golden_dir, "fit_trajectory.npz"))
+    hps = {"batch_size": 64, "epochs": 1, "lr": 0.01}
+    for mode_name in ("fused", "reference_sequential"):
+        rbm = RBM(hps, nh, name="rbm_1", mode=MODE_VISIBLE_BERNOULLI, seed=5, update_mode=mode_name,
+                  weights=(W, b_h, b_v))
+        assert rbm.fit(V) is None
+        assert np.max(np.abs(rbm.rbm_weight - g["W_" + mode_name])) <= TOL
+        assert np.max(np.abs(rbm.hidden_bias - g["bh_" + mode_name])) <= TOL
+        assert np.max(np.abs(rbm.visible_bias - g["bv_" + mode_name])) <= TOL
+        assert np.allclose(rbm.last_scores, g["scores_" + mode_name], rtol=1e-3, atol=1e-3)
+        out = capsys.readouterr().out
+        assert "1 / 1  epochs" in out and "3/3, score:" in out          # rbm.py:115, :234
+
+
+def test_rbm_transform_surface(gpu_device):
+    from keras_unsupervised_amd.ebm import MODE_VISIBLE_BERNOULLI, RBM
+    nv, nh = 40, 24
+    W, b_h, b_v = synthetic_params(nv, nh, seed=3)
+    V = synthetic_binary(10, nv, seed=4)
+    rbm = RBM({"batch_size": 4, "epochs": 1, "lr": 0.1}, nh, mode=MODE_VISIBLE_BERNOULLI, seed=11, weights=(W, b_h, b_v))
+    rbm.build((None, nv))
+    H = rbm.transform(V)
+    assert isinstance(H, list) and len(H) == 1 and H[0].shape == (10, nh)      # K.function list return
+    assert np.array_equal(H[0], O.transform(W, b_h, V, 11, 0))
+    Vr = rbm.inv_transform(H)                                                  # accepts the list form
+    assert np.array_equal(Vr[0], O.inv_transform(W, b_v, H[0], 11, 1))
+    fe = rbm.cal_free_energy([V])
+    assert rel_err(fe[0], O.free_energy(V, W, b_h, b_v)) <= TOL
+    assert rbm(V).shape == (10, nh)
+    assert rbm.compute_output_shape((7, nv)) == (7, nh)
+    cfg = rbm.get_config()
+    assert cfg["output_dim"] == nh and cfg["mode"] == MODE_VISIBLE_BERNOULLI
+
+
+def test_dbn_golden(gpu_device, golden_dir, capsys):
+    from keras_unsupervised_amd.ebm import DBN, MODE_VISIBLE_BERNOULLI, RBM
+    g = np.load(os.path.join(golden_dir, "dbn_small.npz"))
+    Vd = synthetic_binary(40, 32, seed=41, p=0.4)
+    hps = {"batch_size": 16, "epochs": 2, "lr": 0.02}
+    l0 = RBM(hps, 24, name="l0", mode=MODE_VISIBLE_BERNOULLI, seed=1, weights=synthetic_params(32, 24, seed=42))
+    l1 = RBM(hps, 16, name="l1", mode=MODE_VISIBLE_BERNOULLI, seed=2, weights=synthetic_params(24, 16, seed=43))
+    dbn = DBN()
+    dbn.add_stack(l0)
+    dbn.add_stack(l1)
+    dbn.fit(Vd, verbose=0)
+    assert "Train l0." in capsys.readouterr().out                               # dbn.py:53
+    assert np.max(np.abs(l0.rbm_weight - g["W0"])) <= TOL
+    assert np.max(np.abs(l1.rbm_weight - g["W1"])) <= TOL
+    assert np.max(np.abs(l1.hidden_bias - g["bh1"])) <= TOL
+    feat = dbn.transform(Vd)
+    assert np.array_equal(feat, g["feat"].astype(np.float32))
+    back = dbn.inv_transform(feat)
+    assert np.array_equal(back, g["back"].astype(np.float32))
+    bad = RBM(hps, 8, mode=MODE_VISIBLE_BERNOULLI)
+    bad.build((None, 99))
+    with pytest.raises(ValueError):
+        dbn.add_stack(bad)                                                      # dbn.py:29-30
+    with pytest.raises(ValueError):
+        DBN().fit(Vd)                                                           # dbn.py:47-48
+
+
+def test_c_abi_error_behaviour(gpu_device):
+    """Bad arguments come back as error codes with a message, never as a fault."""
+    from keras_unsupervised_amd import _lib
+    W, b_h, b_v = synthetic_params(16, 8, seed=1)
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(synthetic_binary(8, 16, seed=2), gpu_device)
+    with pytest.raises(_lib.KurbmError, match="multiple of 4"):
+        e.half_step("vh", vd, 8, 0, 0, 1, 1, 0, 0, row0=2)
+    with pytest.raises(_lib.KurbmError, match="k must be"):
+        e.cd_step(vd, 8, 0, 0.1, 1, 0, k=0)
+    with pytest.raises(ValueError):
+        e.half_step("hv", vd, 8, 0, 0, 1, 1, 0, 0)      # 16 columns into an 8-wide hidden layer
