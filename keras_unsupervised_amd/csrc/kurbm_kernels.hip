@@ -92,7 +92,9 @@ struct Stage {
     static constexpr int CHUNKS = BX * BK / 4;
     static constexpr int ITERS = (CHUNKS + NTHREADS - 1) / NTHREADS;
     static constexpr int TILE_FLOATS = KMAJOR ? BK * LDK : BX * LDX;
-    f32x4 r[ITERS];
+    f32x4 r[ITERS];          // the tile in flight, 16 B per chunk
+    unsigned goff[ITERS];    // per-lane element offset of each chunk from (src + tile origin)
+    int soff[ITERS];         // per-lane float offset of each chunk in the LDS tile
 
     // chunk q of the tile -> (k, x) of its first element; consecutive lanes walk the
     // contiguous memory direction, so a wave reads whole 128-B (x-major) / 512-B (k-major) runs
@@ -101,11 +103,42 @@ struct Stage {
         else        { xx = q / (BK / 4); kk = 4 * (q % (BK / 4)); }
     }
 
-    // Issue the global loads of one tile.  Branch-free on purpose: out-of-range chunks read
-    // element 0 of the matrix (always mapped) and are zeroed in store(); a conditional load
-    // makes hipcc wait vmcnt(0) right behind every load, which serialises the tile's fetches.
-    __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int x0, int X, int k0,
-                                         int kend, int tid) {
+    // Per-lane offsets for the full-tile fast path.  Chunks whose x lies outside [0, X) are
+    // pointed at x = 0: they only ever feed output rows/columns the epilogue never stores.
+    __device__ __forceinline__ void init(int ld, int x0, int X, int tid) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int q = it * NTHREADS + tid;
+            int kk, xx;
+            coords(q, kk, xx);
+            const int x = (x0 + xx < X) ? x0 + xx : 0;
+            goff[it] = KMAJOR ? (unsigned)(kk * ld + x) : (unsigned)(x * ld + kk);
+            soff[it] = KMAJOR ? kk * LDK + xx : xx * LDX + kk;
+        }
+    }
+
+    // Fast path, tiles with k0 + BK <= kend: no masks, no per-load address arithmetic.
+    // `origin` = src + k0 (x-major) or src + k0 * ld (k-major), wave-uniform.
+    __device__ __forceinline__ void load_full(const float* __restrict__ origin, int tid) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+            if ((CHUNKS % NTHREADS == 0) || it * NTHREADS + tid < CHUNKS)
+                r[it] = *reinterpret_cast<const f32x4*>(origin + goff[it]);
+    }
+
+    template <bool SIGNED>
+    __device__ __forceinline__ void store_full(float* __restrict__ s, float sgn, int tid) const {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+            if ((CHUNKS % NTHREADS == 0) || it * NTHREADS + tid < CHUNKS)
+                *reinterpret_cast<f32x4*>(s + soff[it]) = SIGNED ? r[it] * sgn : r[it];
+    }
+
+    // Masked path for the k-tail tile.  Branch-free loads: out-of-range chunks read element 0
+    // of the matrix (always mapped) and are zeroed in store_masked(); a conditional load makes
+    // hipcc wait vmcnt(0) right behind every load, which serialises the tile's fetches.
+    __device__ __forceinline__ void load_masked(const float* __restrict__ src, int ld, int x0, int X, int k0,
+                                                int kend, int tid) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int q = it * NTHREADS + tid;
@@ -118,9 +151,9 @@ struct Stage {
         }
     }
 
-    // Mask what lies outside [0,X) x [0,kend), apply the segment sign, write the LDS tile.
-    __device__ __forceinline__ void store(float* __restrict__ s, int x0, int X, int k0, int kend, float sgn,
-                                          int tid) const {
+    // Zero what lies outside [0,X) x [0,kend), apply the segment sign, write the LDS tile.
+    __device__ __forceinline__ void store_masked(float* __restrict__ s, int x0, int X, int k0, int kend, float sgn,
+                                                 int tid) const {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int q = it * NTHREADS + tid;
@@ -216,30 +249,47 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
     float* sA0 = smem;
     float* sB0 = smem + 2 * A_FL;
 
-    // tile t of the concatenated k space -> (segment, k0)
+    sa.init(g.lda, m0, g.M, tid);
+    sb.init(g.ldb, n0, g.N, tid);
+    constexpr bool SIGNED = (EPI == EPI_SLAB);   // only the statistics GEMM has a negative segment
+
+    // tile t of the concatenated k space -> (segment, k0); a tile is "full" when all its k are valid
     auto issue = [&](int t) {
         const int seg = (t >= nkt) ? 1 : 0;
         const int k0 = (t - seg * nkt) * BK;
-        sa.load(seg ? g.A1 : g.A0, g.lda, m0, g.M, k0, g.K, tid);
-        sb.load(seg ? g.B1 : g.B0, g.ldb, n0, g.N, k0, g.K, tid);
+        const float* A = seg ? g.A1 : g.A0;
+        const float* B = seg ? g.B1 : g.B0;
+        if (k0 + BK <= g.K) {
+            sa.load_full(A + (A_KM ? (size_t)k0 * g.lda : (size_t)k0), tid);
+            sb.load_full(B + (B_KM ? (size_t)k0 * g.ldb : (size_t)k0), tid);
+        } else {
+            sa.load_masked(A, g.lda, m0, g.M, k0, g.K, tid);
+            sb.load_masked(B, g.ldb, n0, g.N, k0, g.K, tid);
+        }
     };
     auto commit = [&](int t, int buf) {
         const int seg = (t >= nkt) ? 1 : 0;
         const int k0 = (t - seg * nkt) * BK;
-        sa.store(sA0 + buf * A_FL, m0, g.M, k0, g.K, seg ? -1.0f : 1.0f, tid);
-        sb.store(sB0 + buf * B_FL, n0, g.N, k0, g.K, 1.0f, tid);
+        const float sgn = seg ? -1.0f : 1.0f;
+        if (k0 + BK <= g.K) {
+            sa.template store_full<SIGNED>(sA0 + buf * A_FL, sgn, tid);
+            sb.template store_full<false>(sB0 + buf * B_FL, 1.0f, tid);
+        } else {
+            sa.store_masked(sA0 + buf * A_FL, m0, g.M, k0, g.K, sgn, tid);
+            sb.store_masked(sB0 + buf * B_FL, n0, g.N, k0, g.K, 1.0f, tid);
+        }
     };
 
     if (nt > 0) {
         issue(t_begin);
         commit(t_begin, 0);
         __syncthreads();
-        if (nt > 1) issue(t_begin + 1);
         for (int i = 0; i < nt; ++i) {
             const int cur = i & 1;
-            // tile i+1 was fetched during the MFMAs of tile i-1; park it in the other buffer
-            if (i + 1 < nt) commit(t_begin + i + 1, cur ^ 1);
-            if (i + 2 < nt) issue(t_begin + i + 2);
+            const bool more = i + 1 < nt;
+            // fetch tile i+1 into registers now; it is parked in the other LDS buffer after the
+            // MFMAs of tile i, so its latency hides behind them and one register set suffices
+            if (more) issue(t_begin + i + 1);
             const float* cA = sA0 + cur * A_FL;
             const float* cB = sB0 + cur * B_FL;
 #pragma unroll
@@ -255,6 +305,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
                         for (int ni = 0; ni < TN; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi][e], fb[ni][e], acc[mi][ni], 0, 0, 0);
             }
+            if (more) commit(t_begin + i + 1, cur ^ 1);
             __syncthreads();
         }
     }
