@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libkurbm.so")
+# KURBM_LIB selects another build of the same ABI (the s_memtime diagnostic build); never a fallback
+LIB_PATH = os.environ.get("KURBM_LIB") or os.path.join(_HERE, "csrc", "libkurbm.so")
 
 KURBM_OK = 0
 ACT_SIGMOID, ACT_RELU, ACT_LINEAR = 0, 1, 2

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -17,7 +18,15 @@ using namespace kurbm;
 struct kurbm_ctx {
     int device;
     int ncu;
+    // tuning overrides (environment, read once at ctx creation): -1 = automatic
+    int force_cfg[3];   // per layout: KURBM_CFG_VH / KURBM_CFG_HV / KURBM_CFG_OUTER
+    int force_split;    // KURBM_SPLIT
 };
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 
 static thread_local std::string g_err;
 
@@ -64,10 +73,17 @@ static RngArgs make_rng(uint64_t seed, uint64_t row0, uint32_t stream_id, uint32
 // ---- planning -------------------------------------------------------------------------
 // cost of covering an M x N output with one configuration: full waves of workgroups over the
 // CUs times the tile area (every workgroup runs the same k extent).
-static int pick_cfg(int ncu, int M, int N, int* gm_out, int* gn_out) {
+static int pick_cfg(int ncu, int M, int N, int* gm_out, int* gn_out, int force = -1) {
+    if (force >= 0 && force < CFG_COUNT) {
+        int bm, bn;
+        tile_shape(force, &bm, &bn);
+        *gm_out = ceil_div(M, bm);
+        *gn_out = ceil_div(N, bn);
+        return force;
+    }
     int best = 0;
     long long best_cost = -1, best_blocks = 0;
-    for (int c = 0; c < CFG_COUNT; ++c) {
+    for (int c = 0; c < 3; ++c) {   // automatic choice among the one-wave-per-SIMD tiles
         int bm, bn;
         tile_shape(c, &bm, &bn);
         const long long blocks = (long long)ceil_div(M, bm) * ceil_div(N, bn);
@@ -87,12 +103,14 @@ static int pick_cfg(int ncu, int M, int N, int* gm_out, int* gn_out) {
 struct OuterPlan { int cfg, gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_split, ld_slab; };
 
 // statistics GEMM: output n_vis x n_hid, k = batch rows (two signed segments)
-static OuterPlan plan_outer(int ncu, int rows, int n_vis, int n_hid) {
+static OuterPlan plan_outer(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid) {
+    const int ncu = ctx->ncu;
     OuterPlan pl;
     // tile by least padded area (independent of rows so the slab count is monotone in rows)
     long long best = -1;
     pl.cfg = 0; pl.gm = pl.gn = 1;
-    for (int c = 0; c < CFG_COUNT; ++c) {
+    const int fc = ctx->force_cfg[LAYOUT_OUTER];
+    for (int c = (fc >= 0 ? fc : 0); c < (fc >= 0 ? fc + 1 : 3); ++c) {
         int bm, bn;
         tile_shape(c, &bm, &bn);
         const int gm = ceil_div(n_vis, bm), gn = ceil_div(n_hid, bn);
@@ -102,7 +120,7 @@ static OuterPlan plan_outer(int ncu, int rows, int n_vis, int n_hid) {
     pl.nkt = ceil_div(rows, 32);
     pl.kt_total = 2 * pl.nkt;
     const int tiles = pl.gm * pl.gn;
-    int s = ncu / tiles;
+    int s = ctx->force_split > 0 ? ctx->force_split : ncu / tiles;
     if (s < 1) s = 1;
     if (s > pl.kt_total) s = pl.kt_total;
     pl.nsplit_bound = s;  // monotone in rows: what the workspace reserves
@@ -120,14 +138,14 @@ struct Workspace {
 
 static size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
 
-static Workspace carve(int ncu, void* base, int rows, int n_vis, int n_hid, int k) {
+static Workspace carve(const kurbm_ctx* ctx, void* base, int rows, int n_vis, int n_hid, int k) {
     Workspace w;
     w.ldh = round_up(n_hid, 4);
     w.ldv = round_up(n_vis, 4);
-    w.max_row_tiles = ceil_div(rows, 112);
+    w.max_row_tiles = ceil_div(rows, 64);
     w.ld_part_h = w.ldh;
     w.ld_part_v = w.ldv;
-    const OuterPlan pl = plan_outer(ncu, rows, n_vis, n_hid);
+    const OuterPlan pl = plan_outer(ctx, rows, n_vis, n_hid);
     w.slab_stride = (size_t)n_vis * pl.ld_slab;
     size_t off = 0;
     char* b = static_cast<char*>(base);
@@ -141,7 +159,7 @@ static Workspace carve(int ncu, void* base, int rows, int n_vis, int n_hid, int 
     w.slab = take(w.slab_stride * pl.nsplit_bound);
     (void)k;
     // free energy: row partials [col tiles][round_up(rows,4)] alias the front of the workspace
-    const size_t fe = align_up((size_t)ceil_div(n_hid, 112) * round_up(rows, 4) * 4);
+    const size_t fe = align_up((size_t)ceil_div(n_hid, 64) * round_up(rows, 4) * 4);
     w.bytes = off > fe ? off : fe;
     return w;
 }
@@ -171,7 +189,7 @@ static int half_step(kurbm_ctx* ctx, int layout, const kurbm_params* p, const fl
     g.M = rows; g.N = N; g.K = K;
     g.nkt = ceil_div(K, 32);
     g.kt_total = g.nkt; g.kt_per_split = g.nkt; g.nsplit = 1;
-    const int cfg = pick_cfg(ctx->ncu, rows, N, &g.grid_m, &g.grid_n);
+    const int cfg = pick_cfg(ctx->ncu, rows, N, &g.grid_m, &g.grid_n, ctx->force_cfg[layout]);
     g.bias = (layout == LAYOUT_VH) ? p->b_h : p->b_v;
     g.out_sample = out_sample; g.out_prob = out_prob; g.out_u = out_u; g.ldo = ldo;
     g.ref = ref; g.ldref = ldref; g.colpart = colpart; g.ld_colpart = ld_colpart;
@@ -218,6 +236,10 @@ int kurbm_ctx_create(int device, kurbm_ctx** out) {
     kurbm_ctx* c = new kurbm_ctx;
     c->device = device;
     c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->force_cfg[LAYOUT_VH] = env_int("KURBM_CFG_VH", -1);
+    c->force_cfg[LAYOUT_HV] = env_int("KURBM_CFG_HV", -1);
+    c->force_cfg[LAYOUT_OUTER] = env_int("KURBM_CFG_OUTER", -1);
+    c->force_split = env_int("KURBM_SPLIT", -1);
     *out = c;
     return KURBM_OK;
 }
@@ -268,7 +290,7 @@ int kurbm_half_step_hv_dbg(kurbm_ctx* ctx, const kurbm_params* p, const float* h
 
 size_t kurbm_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int k) {
     if (!ctx || rows <= 0 || n_vis <= 0 || n_hid <= 0) return 0;
-    return carve(ctx->ncu, nullptr, rows, n_vis, n_hid, k).bytes;
+    return carve(ctx, nullptr, rows, n_vis, n_hid, k).bytes;
 }
 
 int kurbm_cd_step(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, int rows, int ldv,
@@ -284,7 +306,7 @@ int kurbm_cd_step(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, i
     if (!workspace || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "workspace is null or misaligned");
     if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Workspace w = carve(ctx->ncu, workspace, rows, p->n_vis, p->n_hid, o->k);
+    const Workspace w = carve(ctx, workspace, rows, p->n_vis, p->n_hid, o->k);
     if (w.bytes > workspace_bytes)
         return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
 
@@ -334,7 +356,7 @@ int kurbm_cd_step(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, i
         return e;
 
     // dW = v_pos^T.h_pos - v_neg^T.h_neg  (rbm.py:125-126) as split-K slabs
-    const OuterPlan pl = plan_outer(ctx->ncu, rows, p->n_vis, p->n_hid);
+    const OuterPlan pl = plan_outer(ctx, rows, p->n_vis, p->n_hid);
     if (need_w)
         if ((e = outer_slabs(ctx, v_batch, w.h_pos, v_last, w.h_neg, rows, p->n_vis, p->n_hid, ldv, w.ldh, w.slab,
                              w.slab_stride, pl, st)))
@@ -387,7 +409,7 @@ int kurbm_free_energy(kurbm_ctx* ctx, const kurbm_params* p, const float* v, int
     g.A0 = v; g.lda = ldv; g.B0 = p->W; g.ldb = p->ldw;
     g.M = rows; g.N = p->n_hid; g.K = p->n_vis;
     g.nkt = ceil_div(g.K, 32); g.kt_total = g.nkt; g.kt_per_split = g.nkt; g.nsplit = 1;
-    const int cfg = pick_cfg(ctx->ncu, rows, g.N, &g.grid_m, &g.grid_n);
+    const int cfg = pick_cfg(ctx->ncu, rows, g.N, &g.grid_m, &g.grid_n, ctx->force_cfg[LAYOUT_VH]);
     g.bias = p->b_h;
     g.rowpart = static_cast<float*>(workspace);
     g.ld_rowpart = round_up(rows, 4);
@@ -411,10 +433,10 @@ int kurbm_outer_delta(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, co
         return fail(KURBM_ERR_ARG, "operand: null, misaligned, ld %% 4 != 0 or ld < columns");
     if (!workspace || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "workspace is null or misaligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Workspace w = carve(ctx->ncu, workspace, rows, n_vis, n_hid, 1);
+    const Workspace w = carve(ctx, workspace, rows, n_vis, n_hid, 1);
     if (w.bytes > workspace_bytes)
         return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
-    const OuterPlan pl = plan_outer(ctx->ncu, rows, n_vis, n_hid);
+    const OuterPlan pl = plan_outer(ctx, rows, n_vis, n_hid);
     if (int e = outer_slabs(ctx, v_pos, h_pos, v_neg, h_neg, rows, n_vis, n_hid, ldv, ldh, w.slab, w.slab_stride, pl, st))
         return e;
     ReduceArgs a;
@@ -428,5 +450,10 @@ int kurbm_outer_delta(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, co
     HIP_TRY(launch_reduce_apply(a, st));
     return KURBM_OK;
 }
+
+#ifdef KURBM_STAMPS
+/* diagnostic library only: not part of include/kurbm.h */
+void kurbm_debug_set_stamp_buffer(void* p) { set_stamp_buffer(static_cast<unsigned long long*>(p)); }
+#endif
 
 }  // extern "C"

@@ -10,7 +10,9 @@ enum { NOISE_NONE = 0, NOISE_BERNOULLI = 1, NOISE_GAUSSIAN = 2 };
 enum { EPI_HALFSTEP = 0, EPI_SLAB = 1, EPI_SOFTPLUS = 2 };
 // operand layouts: VH  A=[m][k] B=[k][n];  HV  A=[m][k] B=[n][k];  OUTER  A=[k][m] B=[k][n]
 enum { LAYOUT_VH = 0, LAYOUT_HV = 1, LAYOUT_OUTER = 2 };
-enum { CFG_128x128 = 0, CFG_128x112 = 1, CFG_112x128 = 2, CFG_COUNT = 3 };
+// tile configurations (BM x BN, waves as WAVES_M x WAVES_N); see tile_shape()
+enum { CFG_128x128 = 0, CFG_128x112 = 1, CFG_112x128 = 2, CFG_128x64 = 3, CFG_64x128 = 4, CFG_64x64 = 5,
+       CFG_64x112 = 6, CFG_112x64 = 7, CFG_COUNT = 8 };
 
 struct RngArgs {
     uint32_t seed_lo, seed_hi;
@@ -50,7 +52,12 @@ struct GemmArgs {
     // softplus epilogue
     float* rowpart;     // [grid_n][ld_rowpart]
     int ld_rowpart;
+    // diagnostic build only (KURBM_STAMPS): 8 x u64 per wave
+    unsigned long long* stamps;
 };
+
+// Diagnostic hook: the next GEMM launches write their s_memtime stamps here (null = off).
+void set_stamp_buffer(unsigned long long* p);
 
 struct ReduceArgs {
     const float* slab;

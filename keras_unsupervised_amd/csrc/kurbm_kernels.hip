@@ -35,6 +35,19 @@
 
 namespace kurbm {
 
+// Diagnostic build only (-DKURBM_STAMPS, libkurbm_stamps.so): s_memtime brackets around the
+// segments of the k loop, written to GemmArgs::stamps.  The shipped library has no stamps.
+#ifdef KURBM_STAMPS
+#define KURBM_STAMP(var)                                                                        \
+    do {                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
+#else
+#define KURBM_STAMP(var) do { } while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;          // k-tile
@@ -48,8 +61,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a mul_hi / mul_lo pair
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -208,7 +223,10 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
     using StA = Stage<BM, A_KM>;
     using StB = Stage<BN, B_KM>;
     constexpr int A_FL = StA::TILE_FLOATS, B_FL = StB::TILE_FLOATS;
-    constexpr int EPI_FL = (EPI == EPI_HALFSTEP) ? WAVES_M * BN : ((EPI == EPI_SOFTPLUS) ? WAVES_N * BM : 0);
+    // epilogue scratch: per-wave transpose patch / column-sum staging (half step), row-sum staging (softplus)
+    constexpr int EPI_FL = (EPI == EPI_HALFSTEP)
+                               ? ((4 * WM * (WN + 4) > WAVES_M * (64 / (WN / 4)) * BN) ? 4 * WM * (WN + 4) : WAVES_M * (64 / (WN / 4)) * BN)
+                               : ((EPI == EPI_SOFTPLUS) ? WAVES_N * BM : 0);
     constexpr int SMEM_FL = (2 * (A_FL + B_FL) > EPI_FL) ? 2 * (A_FL + B_FL) : EPI_FL;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FL];
 
@@ -280,16 +298,24 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
         }
     };
 
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, tsa = 0, tsb = 0, tsc = 0, tsd = 0;
+    unsigned long long seg_issue = 0, seg_mfma = 0, seg_commit = 0, seg_bar = 0;
+    (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)tsa; (void)tsb; (void)tsc; (void)tsd;
+    (void)seg_issue; (void)seg_mfma; (void)seg_commit; (void)seg_bar;
+    KURBM_STAMP(ts0);
     if (nt > 0) {
         issue(t_begin);
         commit(t_begin, 0);
         __syncthreads();
+        KURBM_STAMP(ts1);
         for (int i = 0; i < nt; ++i) {
             const int cur = i & 1;
             const bool more = i + 1 < nt;
+            KURBM_STAMP(tsa);
             // fetch tile i+1 into registers now; it is parked in the other LDS buffer after the
             // MFMAs of tile i, so its latency hides behind them and one register set suffices
             if (more) issue(t_begin + i + 1);
+            KURBM_STAMP(tsb);
             const float* cA = sA0 + cur * A_FL;
             const float* cB = sB0 + cur * B_FL;
 #pragma unroll
@@ -305,10 +331,33 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
                         for (int ni = 0; ni < TN; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi][e], fb[ni][e], acc[mi][ni], 0, 0, 0);
             }
+            KURBM_STAMP(tsc);
             if (more) commit(t_begin + i + 1, cur ^ 1);
+            KURBM_STAMP(tsd);
             __syncthreads();
+#ifdef KURBM_STAMPS
+            {
+                unsigned long long tse;
+                KURBM_STAMP(tse);
+                seg_issue += tsb - tsa; seg_mfma += tsc - tsb; seg_commit += tsd - tsc; seg_bar += tse - tsd;
+            }
+#endif
         }
     }
+    KURBM_STAMP(ts2);
+#ifdef KURBM_STAMPS
+#define KURBM_STAMP_OUT()                                                                        \
+    do {                                                                                         \
+        KURBM_STAMP(ts3);                                                                        \
+        if (g.stamps && lane == 0) {                                                             \
+            unsigned long long* o = g.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;              \
+            o[0] = ts1 - ts0; o[1] = ts2 - ts1; o[2] = ts3 - ts2; o[3] = seg_issue;              \
+            o[4] = seg_mfma; o[5] = seg_commit; o[6] = seg_bar; o[7] = ts0;                      \
+        }                                                                                        \
+    } while (0)
+#else
+#define KURBM_STAMP_OUT() do { } while (0)
+#endif
 
     const int l15 = lane & 15, slot = lane >> 4;
 
@@ -325,24 +374,32 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
                 for (int r = 0; r < 4; ++r)
                     if (rowb + r < g.M && col < g.N) slab[(size_t)(rowb + r) * g.ld_slab + col] = acc[mi][ni][r];
             }
+        KURBM_STAMP_OUT();
         return;
     }
 
     // ---------------- epilogue: bias + activation + draw (+ column-difference partials) -
+    // The draw happens in the accumulator layout (one Philox block = the 4 rows a lane owns in one
+    // 16x16 accumulator).  Every output plane is then transposed through the wave's private LDS
+    // patch so global memory sees whole rows: 16 B per lane, 4*WN contiguous bytes per row, instead
+    // of 64-B fragments -- and the reference plane of the column-difference sums is read the same way.
     if (EPI == EPI_HALFSTEP) {
-        float csum[TN];
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) csum[ni] = 0.f;
+        constexpr int LDE = WN + 4;                 // patch row (floats): +4 keeps b32 writes conflict-free
+        constexpr int LPR = WN / 4;                 // lanes per output row (16 B each)
+        constexpr int RPI = 64 / LPR;               // rows per wave-instruction
+        constexpr int NPASS = (WM + RPI - 1) / RPI;
+        float* patch = smem + wave * (WM * LDE);
         const bool want_diff = (g.ref != nullptr);
+
+        float pv[TM][TN][4], sv[TM][TN][4], uv[TM][TN][4];
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int col = n0 + wn * WN + ni * 16 + l15;
-            const bool cok = col < g.N;
-            const float bias = cok ? g.bias[col] : 0.f;
+            const float bias = (col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
                 const int rowb = m0 + wm * WM + mi * 16 + slot * 4;
-                uint32_t w[4], w2[4];
+                uint32_t w[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
                 if (NOISE != NOISE_NONE) {
                     const uint64_t grow = g.rng.row0 + (uint64_t)rowb;
                     philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step,
@@ -353,49 +410,86 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = rowb + r;
                     const float x = acc[mi][ni][r] + bias;
                     float p;
                     if (g.act == ACT_SIGMOID) p = sigmoidf_fast(x);
                     else if (g.act == ACT_RELU) p = fmaxf(x, 0.f);
                     else p = x;
-                    float s = p;
+                    float sm = p;
+                    const float ua = u32_to_unit(w[r]);
                     if (NOISE == NOISE_BERNOULLI) {
-                        s = (u32_to_unit(w[r]) < p) ? 1.0f : 0.0f;
+                        sm = (ua < p) ? 1.0f : 0.0f;
                     } else if (NOISE == NOISE_GAUSSIAN) {
-                        const float ua = u32_to_unit(w[r]), ub = u32_to_unit(w2[r]);
-                        s = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * ub);
+                        const float ub = u32_to_unit(w2[r]);
+                        sm = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * ub);
                     }
-                    if (row < g.M && cok) {
-                        const size_t o = (size_t)row * g.ldo + col;
-                        if (g.out_prob) g.out_prob[o] = p;
-                        if (g.out_sample) g.out_sample[o] = s;
-                        if (g.out_u && NOISE != NOISE_NONE) g.out_u[o] = u32_to_unit(w[r]);
-                        if (want_diff) csum[ni] += g.ref[(size_t)row * g.ldref + col] - s;
-                    }
+                    pv[mi][ni][r] = p; sv[mi][ni][r] = sm; uv[mi][ni][r] = ua;
                 }
             }
         }
-        if (want_diff) {
-            // rows of one column live in the 4 lane groups (lane >> 4) and in the WAVES_M waves
+
+        float csum[4] = {0.f, 0.f, 0.f, 0.f};
+        const int prow = lane / LPR, pc4 = lane - prow * LPR;   // this lane's place in a pass
+        const bool lane_on = lane < RPI * LPR;
+        const int gcol = n0 + wn * WN + 4 * pc4;
+
+        // one output plane: registers -> patch -> whole-row stores (+ ref - value column sums)
+        auto flush = [&](const float (&val)[TM][TN][4], float* __restrict__ out, bool diff) {
+            __syncthreads();   // patch free: k loop / previous plane finished
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                csum[ni] += __shfl_xor(csum[ni], 16);
-                csum[ni] += __shfl_xor(csum[ni], 32);
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        patch[(mi * 16 + slot * 4 + r) * LDE + ni * 16 + l15] = val[mi][ni][r];
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int lrow = ps * RPI + prow;
+                const int grow = m0 + wm * WM + lrow;
+                if (lane_on && lrow < WM && grow < g.M && gcol < g.N) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(patch + lrow * LDE + 4 * pc4);
+                    const int nval = g.N - gcol;   // >= 1
+                    if (out) {
+                        float* o = out + (size_t)grow * g.ldo + gcol;
+                        if (nval >= 4) *reinterpret_cast<f32x4*>(o) = v;
+                        else { o[0] = v.x; if (nval > 1) o[1] = v.y; if (nval > 2) o[2] = v.z; }
+                    }
+                    if (diff) {
+                        // the ref row is padded to ld % 4 == 0, so the 16-B read stays inside it
+                        const f32x4 rf = *reinterpret_cast<const f32x4*>(g.ref + (size_t)grow * g.ldref + gcol);
+                        csum[0] += rf.x - v.x;
+                        if (nval > 1) csum[1] += rf.y - v.y;
+                        if (nval > 2) csum[2] += rf.z - v.z;
+                        if (nval > 3) csum[3] += rf.w - v.w;
+                    }
+                }
             }
-            // smem is free: the k loop ended on a barrier
-            if (slot == 0) {
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) smem[wm * BN + wn * WN + ni * 16 + l15] = csum[ni];
+        };
+        const bool diff_on_sample = (NOISE != NOISE_NONE);
+        if (g.out_prob || (want_diff && !diff_on_sample)) flush(pv, g.out_prob, want_diff && !diff_on_sample);
+        if (NOISE != NOISE_NONE && (g.out_sample || want_diff)) flush(sv, g.out_sample, want_diff);
+        if (NOISE != NOISE_NONE && g.out_u) flush(uv, g.out_u, false);
+
+        if (want_diff) {
+            // column partials of this workgroup: sum over the RPI row groups of each wave and the
+            // WAVES_M waves that share a column, in a fixed order (bit-reproducible)
+            __syncthreads();
+            float* red = smem;   // [WAVES_M * RPI][BN]
+            if (lane_on) {
+                float* dst = red + (wm * RPI + prow) * BN + wn * WN + 4 * pc4;
+                dst[0] = csum[0]; dst[1] = csum[1]; dst[2] = csum[2]; dst[3] = csum[3];
             }
             __syncthreads();
             if (tid < BN) {
                 float t = 0.f;
 #pragma unroll
-                for (int i = 0; i < WAVES_M; ++i) t += smem[i * BN + tid];
+                for (int i = 0; i < WAVES_M * RPI; ++i) t += red[i * BN + tid];
                 if (n0 + tid < g.N) g.colpart[(size_t)bm * g.ld_colpart + n0 + tid] = t;
             }
         }
+        KURBM_STAMP_OUT();
         return;
     }
 
@@ -526,19 +620,30 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
 }
 
 void tile_shape(int cfg, int* bm, int* bn) {
-    switch (cfg) {
-        case CFG_128x128: *bm = 128; *bn = 128; break;
-        case CFG_128x112: *bm = 128; *bn = 112; break;
-        default: *bm = 112; *bn = 128; break;
-    }
+    static const int shapes[CFG_COUNT][2] = {{128, 128}, {128, 112}, {112, 128}, {128, 64}, {64, 128}, {64, 64}, {64, 112}, {112, 64}};
+    *bm = shapes[cfg][0];
+    *bn = shapes[cfg][1];
 }
 
-hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g, hipStream_t st) {
+static unsigned long long* g_stamp_buffer = nullptr;
+void set_stamp_buffer(unsigned long long* p) { g_stamp_buffer = p; }
+
+hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g_in, hipStream_t st) {
+    GemmArgs g = g_in;
+    g.stamps = g_stamp_buffer;
 #define KURBM_CASE(L, AK, BKM, E, NZ)                                                               \
     if (layout == L && epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) {                          \
-        if (cfg == CFG_128x128) return launch_cfg<128, 128, 2, 2, AK, BKM, E, NZ>(g, st);            \
-        if (cfg == CFG_128x112) return launch_cfg<128, 112, 4, 1, AK, BKM, E, NZ>(g, st);            \
-        if (cfg == CFG_112x128) return launch_cfg<112, 128, 1, 4, AK, BKM, E, NZ>(g, st);            \
+        switch (cfg) {                                                                              \
+            case CFG_128x128: return launch_cfg<128, 128, 2, 2, AK, BKM, E, NZ>(g, st);             \
+            case CFG_128x112: return launch_cfg<128, 112, 4, 1, AK, BKM, E, NZ>(g, st);             \
+            case CFG_112x128: return launch_cfg<112, 128, 1, 4, AK, BKM, E, NZ>(g, st);             \
+            case CFG_128x64: return launch_cfg<128, 64, 2, 2, AK, BKM, E, NZ>(g, st);               \
+            case CFG_64x128: return launch_cfg<64, 128, 2, 2, AK, BKM, E, NZ>(g, st);               \
+            case CFG_64x64: return launch_cfg<64, 64, 2, 2, AK, BKM, E, NZ>(g, st);                 \
+            case CFG_64x112: return launch_cfg<64, 112, 4, 1, AK, BKM, E, NZ>(g, st);               \
+            case CFG_112x64: return launch_cfg<112, 64, 1, 4, AK, BKM, E, NZ>(g, st);               \
+            default: return hipErrorInvalidValue;                                                   \
+        }                                                                                           \
     }
     KURBM_CASE(LAYOUT_VH, false, true, EPI_HALFSTEP, NOISE_NONE)
     KURBM_CASE(LAYOUT_VH, false, true, EPI_HALFSTEP, NOISE_BERNOULLI)
