@@ -117,15 +117,16 @@ static OuterPlan plan_outer(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid
         const long long area = (long long)gm * gn * bm * bn;
         if (best < 0 || area < best) { best = area; pl.cfg = c; pl.gm = gm; pl.gn = gn; }
     }
-    pl.nkt = ceil_div(rows, 32);
+    pl.nkt = rows / 32;          // full k-tiles per segment; a rows % 32 tail goes to the last slice
     pl.kt_total = 2 * pl.nkt;
     const int tiles = pl.gm * pl.gn;
     int s = ctx->force_split > 0 ? ctx->force_split : ncu / tiles;
     if (s < 1) s = 1;
     if (s > pl.kt_total) s = pl.kt_total;
+    if (s < 1) s = 1;
     pl.nsplit_bound = s;  // monotone in rows: what the workspace reserves
-    pl.kt_per_split = ceil_div(pl.kt_total, s);
-    pl.nsplit = ceil_div(pl.kt_total, pl.kt_per_split);
+    pl.kt_per_split = pl.kt_total > 0 ? ceil_div(pl.kt_total, s) : 0;
+    pl.nsplit = pl.kt_total > 0 ? ceil_div(pl.kt_total, pl.kt_per_split) : 1;
     pl.ld_slab = round_up(n_hid, 4);
     return pl;
 }
@@ -187,7 +188,8 @@ static int half_step(kurbm_ctx* ctx, int layout, const kurbm_params* p, const fl
     g.A0 = in; g.lda = ld_in;
     g.B0 = p->W; g.ldb = p->ldw;
     g.M = rows; g.N = N; g.K = K;
-    g.nkt = ceil_div(K, 32);
+    g.nseg = 1;
+    g.nkt = K / 32;
     g.kt_total = g.nkt; g.kt_per_split = g.nkt; g.nsplit = 1;
     const int cfg = pick_cfg(ctx->ncu, rows, N, &g.grid_m, &g.grid_n, ctx->force_cfg[layout]);
     g.bias = (layout == LAYOUT_VH) ? p->b_h : p->b_v;
@@ -209,6 +211,7 @@ static int outer_slabs(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, c
     g.A0 = v_pos; g.A1 = v_neg; g.lda = ldv;
     g.B0 = h_pos; g.B1 = h_neg; g.ldb = ldh;
     g.M = n_vis; g.N = n_hid; g.K = rows;
+    g.nseg = 2;
     g.nkt = pl.nkt; g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
     g.grid_m = pl.gm; g.grid_n = pl.gn;
     g.slab = slab; g.slab_stride = slab_stride; g.ld_slab = pl.ld_slab;
@@ -408,7 +411,8 @@ int kurbm_free_energy(kurbm_ctx* ctx, const kurbm_params* p, const float* v, int
     memset(&g, 0, sizeof g);
     g.A0 = v; g.lda = ldv; g.B0 = p->W; g.ldb = p->ldw;
     g.M = rows; g.N = p->n_hid; g.K = p->n_vis;
-    g.nkt = ceil_div(g.K, 32); g.kt_total = g.nkt; g.kt_per_split = g.nkt; g.nsplit = 1;
+    g.nseg = 1;
+    g.nkt = g.K / 32; g.kt_total = g.nkt; g.kt_per_split = g.nkt; g.nsplit = 1;
     const int cfg = pick_cfg(ctx->ncu, rows, g.N, &g.grid_m, &g.grid_n, ctx->force_cfg[LAYOUT_VH]);
     g.bias = p->b_h;
     g.rowpart = static_cast<float*>(workspace);

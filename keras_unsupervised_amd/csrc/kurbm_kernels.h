@@ -28,10 +28,11 @@ struct GemmArgs {
     const float* B1;
     int lda, ldb;
     int M, N, K;        // K = extent of k per segment
-    int nkt;            // k-tiles per segment  = ceil(K / 32)
-    int kt_total;       // k-tiles over all segments
-    int kt_per_split;   // k-tiles per split-K slice
-    int nsplit;
+    int nseg;           // 1, or 2 for the statistics GEMM
+    int nkt;            // FULL k-tiles per segment = K / 32 (the K % 32 tail is handled apart)
+    int kt_total;       // full k-tiles over all segments = nseg * nkt
+    int kt_per_split;   // full k-tiles per split-K slice
+    int nsplit;         // slices; the last one also takes the tail tiles
     int grid_m, grid_n;
     // half-step epilogue
     const float* bias;

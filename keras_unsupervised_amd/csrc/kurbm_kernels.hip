@@ -103,13 +103,17 @@ __global__ void k_philox_uniform(float* __restrict__ out, int rows, int cols, in
 // ------------------------------------------------------------------------------------
 template <int BX, bool KMAJOR>
 struct Stage {
-    static constexpr int LDK = BX + 4;  // k-major LDS row (floats); (BX+4) % 8 == 4 for BX in {112,128}
-    static constexpr int CHUNKS = BX * BK / 4;
+    static constexpr int LDK = BX + 4;  // k-major LDS row (floats); (BX+4) % 8 == 4 for BX in {64,112,128}
+    static constexpr int CHUNKS = BX * BK / 4;   // 16-B chunks per tile
     static constexpr int ITERS = (CHUNKS + NTHREADS - 1) / NTHREADS;
     static constexpr int TILE_FLOATS = KMAJOR ? BK * LDK : BX * LDX;
-    f32x4 r[ITERS];          // the tile in flight, 16 B per chunk
+    static constexpr bool RAGGED = (CHUNKS % NTHREADS) != 0;   // last chunk only for some lanes
+
+    struct Regs { f32x4 r[ITERS]; };   // one tile in flight, 16 B per chunk
+
     unsigned goff[ITERS];    // per-lane element offset of each chunk from (src + tile origin)
     int soff[ITERS];         // per-lane float offset of each chunk in the LDS tile
+    int tid;
 
     // chunk q of the tile -> (k, x) of its first element; consecutive lanes walk the
     // contiguous memory direction, so a wave reads whole 128-B (x-major) / 512-B (k-major) runs
@@ -120,7 +124,8 @@ struct Stage {
 
     // Per-lane offsets for the full-tile fast path.  Chunks whose x lies outside [0, X) are
     // pointed at x = 0: they only ever feed output rows/columns the epilogue never stores.
-    __device__ __forceinline__ void init(int ld, int x0, int X, int tid) {
+    __device__ __forceinline__ void init(int ld, int x0, int X, int tid_) {
+        tid = tid_;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int q = it * NTHREADS + tid;
@@ -132,43 +137,38 @@ struct Stage {
         }
     }
 
-    // Fast path, tiles with k0 + BK <= kend: no masks, no per-load address arithmetic.
-    // `origin` = src + k0 (x-major) or src + k0 * ld (k-major), wave-uniform.
-    __device__ __forceinline__ void load_full(const float* __restrict__ origin, int tid) {
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it)
-            if ((CHUNKS % NTHREADS == 0) || it * NTHREADS + tid < CHUNKS)
-                r[it] = *reinterpret_cast<const f32x4*>(origin + goff[it]);
-    }
+    __device__ __forceinline__ bool lane_has(int it) const { return !RAGGED || it * NTHREADS + tid < CHUNKS; }
 
+    // Fast path (tiles whose 32 k are all valid): one chunk, no masks, no address arithmetic
+    // beyond origin + offset.  `origin` = src + k0 (x-major) or src + k0 * ld (k-major), uniform.
+    __device__ __forceinline__ void load_chunk(Regs& R, const float* __restrict__ origin, int it) const {
+        if (lane_has(it)) R.r[it] = *reinterpret_cast<const f32x4*>(origin + goff[it]);
+    }
     template <bool SIGNED>
-    __device__ __forceinline__ void store_full(float* __restrict__ s, float sgn, int tid) const {
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it)
-            if ((CHUNKS % NTHREADS == 0) || it * NTHREADS + tid < CHUNKS)
-                *reinterpret_cast<f32x4*>(s + soff[it]) = SIGNED ? r[it] * sgn : r[it];
+    __device__ __forceinline__ void park_chunk(const Regs& R, float* __restrict__ s, float sgn, int it) const {
+        if (lane_has(it)) *reinterpret_cast<f32x4*>(s + soff[it]) = SIGNED ? R.r[it] * sgn : R.r[it];
     }
 
     // Masked path for the k-tail tile.  Branch-free loads: out-of-range chunks read element 0
-    // of the matrix (always mapped) and are zeroed in store_masked(); a conditional load makes
+    // of the matrix (always mapped) and are zeroed in park_masked(); a conditional load makes
     // hipcc wait vmcnt(0) right behind every load, which serialises the tile's fetches.
-    __device__ __forceinline__ void load_masked(const float* __restrict__ src, int ld, int x0, int X, int k0,
-                                                int kend, int tid) {
+    __device__ __forceinline__ void load_masked(Regs& R, const float* __restrict__ src, int ld, int x0, int X,
+                                                int k0, int kend) const {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int q = it * NTHREADS + tid;
             int kk, xx;
             coords(q, kk, xx);
             const int k = k0 + kk, x = x0 + xx;
-            const bool ok = (k < kend) & (x < X) & ((CHUNKS % NTHREADS == 0) | (q < CHUNKS));
+            const bool ok = (k < kend) & (x < X) & (!RAGGED | (q < CHUNKS));
             const size_t off = KMAJOR ? ((size_t)k * ld + x) : ((size_t)x * ld + k);
-            r[it] = *reinterpret_cast<const f32x4*>(src + (ok ? off : (size_t)0));
+            R.r[it] = *reinterpret_cast<const f32x4*>(src + (ok ? off : (size_t)0));
         }
     }
 
     // Zero what lies outside [0,X) x [0,kend), apply the segment sign, write the LDS tile.
-    __device__ __forceinline__ void store_masked(float* __restrict__ s, int x0, int X, int k0, int kend, float sgn,
-                                                 int tid) const {
+    __device__ __forceinline__ void park_masked(const Regs& R, float* __restrict__ s, int x0, int X, int k0,
+                                                int kend, float sgn) const {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int q = it * NTHREADS + tid;
@@ -177,12 +177,12 @@ struct Stage {
             const int k = k0 + kk, x = x0 + xx;
             const bool ok = (k < kend) & (x < X);
             const int lim = KMAJOR ? (X - x) : (kend - k);  // valid elements along the contiguous direction
-            f32x4 v = r[it];
+            f32x4 v = R.r[it];
             v.x = ok ? v.x * sgn : 0.f;
             v.y = (ok & (lim > 1)) ? v.y * sgn : 0.f;
             v.z = (ok & (lim > 2)) ? v.z * sgn : 0.f;
             v.w = (ok & (lim > 3)) ? v.w * sgn : 0.f;
-            if ((CHUNKS % NTHREADS == 0) || q < CHUNKS)
+            if (!RAGGED || q < CHUNKS)
                 *reinterpret_cast<f32x4*>(s + (KMAJOR ? kk * LDK + xx : xx * LDX + kk)) = v;
         }
     }
@@ -249,12 +249,15 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
     const int bm = tmn / g.grid_n, bn = tmn - bm * g.grid_n;
     const int m0 = bm * BM, n0 = bn * BN;
 
-    // k-tiles [t_begin, t_end) of the concatenated segments
-    const int nkt = g.nkt;  // k-tiles per segment
+    // k space: `nseg` segments of extent K; each has nfull = K / 32 full tiles (+ one partial
+    // "tail" tile when K % 32 != 0).  The full tiles of all segments form one list that is split
+    // over the z slices; the last slice also takes the tail tiles.
+    const int nfull = g.nkt;
     const int t_begin = z * g.kt_per_split;
     int t_end = t_begin + g.kt_per_split;
     if (t_end > g.kt_total) t_end = g.kt_total;
-    const int nt = t_end - t_begin;
+    const int nt = t_end > t_begin ? t_end - t_begin : 0;
+    const bool do_tail = (g.K & (BK - 1)) != 0 && z == g.nsplit - 1;
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -264,86 +267,142 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
 
     StA sa;
     StB sb;
-    float* sA0 = smem;
-    float* sB0 = smem + 2 * A_FL;
-
     sa.init(g.lda, m0, g.M, tid);
     sb.init(g.ldb, n0, g.N, tid);
+    typename StA::Regs ra0, ra1;   // two tiles in flight: one being parked, one being fetched
+    typename StB::Regs rb0, rb1;
+    float* sA0 = smem;
+    float* sB0 = smem + 2 * A_FL;
     constexpr bool SIGNED = (EPI == EPI_SLAB);   // only the statistics GEMM has a negative segment
+    constexpr int NA = StA::ITERS, NB = StB::ITERS, NCH = NA + NB;
+    static_assert(NCH <= 8, "one fetch per MFMA group");
 
-    // tile t of the concatenated k space -> (segment, k0); a tile is "full" when all its k are valid
-    auto issue = [&](int t) {
-        const int seg = (t >= nkt) ? 1 : 0;
-        const int k0 = (t - seg * nkt) * BK;
-        const float* A = seg ? g.A1 : g.A0;
-        const float* B = seg ? g.B1 : g.B0;
-        if (k0 + BK <= g.K) {
-            sa.load_full(A + (A_KM ? (size_t)k0 * g.lda : (size_t)k0), tid);
-            sb.load_full(B + (B_KM ? (size_t)k0 * g.ldb : (size_t)k0), tid);
-        } else {
-            sa.load_masked(A, g.lda, m0, g.M, k0, g.K, tid);
-            sb.load_masked(B, g.ldb, n0, g.N, k0, g.K, tid);
-        }
-    };
-    auto commit = [&](int t, int buf) {
-        const int seg = (t >= nkt) ? 1 : 0;
-        const int k0 = (t - seg * nkt) * BK;
-        const float sgn = seg ? -1.0f : 1.0f;
-        if (k0 + BK <= g.K) {
-            sa.template store_full<SIGNED>(sA0 + buf * A_FL, sgn, tid);
-            sb.template store_full<false>(sB0 + buf * B_FL, 1.0f, tid);
-        } else {
-            sa.store_masked(sA0 + buf * A_FL, m0, g.M, k0, g.K, sgn, tid);
-            sb.store_masked(sB0 + buf * B_FL, n0, g.N, k0, g.K, 1.0f, tid);
-        }
-    };
-
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, tsa = 0, tsb = 0, tsc = 0, tsd = 0;
-    unsigned long long seg_issue = 0, seg_mfma = 0, seg_commit = 0, seg_bar = 0;
-    (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)tsa; (void)tsb; (void)tsc; (void)tsd;
-    (void)seg_issue; (void)seg_mfma; (void)seg_commit; (void)seg_bar;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    (void)ts0; (void)ts1; (void)ts2; (void)ts3;
     KURBM_STAMP(ts0);
+
+    // full tile t (clamped to the slice) -> operand origins and sign
+    auto tile_of = [&](int t, const float*& oa, const float*& ob, float& sgn) {
+        t = t < t_end ? t : t_end - 1;
+        const int seg = (t >= nfull) ? 1 : 0;
+        const size_t k0 = (size_t)(t - seg * nfull) * BK;
+        oa = (seg ? g.A1 : g.A0) + (A_KM ? k0 * g.lda : k0);
+        ob = (seg ? g.B1 : g.B0) + (B_KM ? k0 * g.ldb : k0);
+        sgn = seg ? -1.0f : 1.0f;
+    };
+    auto mfma_group = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN], int e) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi][e], fb[ni][e], acc[mi][ni], 0, 0, 0);
+    };
+
+    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];   // fragments: k 0..15 and k 16..31 of the current tile
+    f32x4 na0[TM], nb0[TN];                     // k 0..15 of the next tile (prefetched)
+
+    // One k-tile, software pipelined over its 8 MFMA groups (group = one of the 8 k-steps of 4):
+    //   * tile i+2 is fetched from global memory, one 16-B chunk per group        (regs L)
+    //   * tile i+1, fetched during the previous tile, is parked in the other LDS
+    //     buffer during groups 0..5                                                (regs P)
+    //   * ONE barrier per tile, after group 5: by then every wave has read all its fragments
+    //     of the current buffer (k 16..31 are read in group 1) and written its share of the
+    //     next one, so groups 6-7 can already prefetch the next tile's first fragments.
+    // sched_barrier(0) pins this order; inside a group hipcc schedules freely.
+    auto pipelined_tile = [&](int i, int cur, typename StA::Regs& LA, typename StB::Regs& LB,
+                              const typename StA::Regs& PA, const typename StB::Regs& PB) {
+        const float *oa, *ob, *pa_, *pb_;
+        float sgn_l, sgn_p;
+        tile_of(t_begin + i + 2, oa, ob, sgn_l);
+        tile_of(t_begin + i + 1, pa_, pb_, sgn_p);
+        (void)sgn_l; (void)pa_; (void)pb_;
+        const float* cA = sA0 + cur * A_FL;
+        const float* cB = sB0 + cur * B_FL;
+        float* nA = sA0 + (cur ^ 1) * A_FL;
+        float* nB = sB0 + (cur ^ 1) * B_FL;
+#pragma unroll
+        for (int grp = 0; grp < 8; ++grp) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp < NCH) {   // fetch chunk `grp` of tile i+2
+                if (grp < NA) sa.load_chunk(LA, oa, grp);
+                else sb.load_chunk(LB, ob, grp - NA);
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)   // park the chunks of tile i+1 assigned to this group
+                if ((c * 6) / NCH == grp) {
+                    if (c < NA) sa.template park_chunk<SIGNED>(PA, nA, sgn_p, c);
+                    else sb.template park_chunk<false>(PB, nB, 1.0f, c - NA);
+                }
+            if (grp == 1) {
+                fetch_frags<BM, A_KM, TM>(cA, wm * WM, 1, lane, fa1);
+                fetch_frags<BN, B_KM, TN>(cB, wn * WN, 1, lane, fb1);
+            }
+            if (grp == 6) {
+                fetch_frags<BM, A_KM, TM>(nA, wm * WM, 0, lane, na0);
+                fetch_frags<BN, B_KM, TN>(nB, wn * WN, 0, lane, nb0);
+            }
+            if (grp < 4) mfma_group(fa0, fb0, grp);
+            else mfma_group(fa1, fb1, grp - 4);
+            if (grp == 5) __syncthreads();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < TM; ++q) fa0[q] = na0[q];
+#pragma unroll
+        for (int q = 0; q < TN; ++q) fb0[q] = nb0[q];
+    };
+
     if (nt > 0) {
-        issue(t_begin);
-        commit(t_begin, 0);
+        // fill: tile 0 -> LDS buffer 0, tile 1 -> registers (set 1), first fragments of tile 0
+        const float *oa, *ob;
+        float sgn;
+        tile_of(t_begin, oa, ob, sgn);
+#pragma unroll
+        for (int c = 0; c < NA; ++c) sa.load_chunk(ra0, oa, c);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) sb.load_chunk(rb0, ob, c);
+#pragma unroll
+        for (int c = 0; c < NA; ++c) sa.template park_chunk<SIGNED>(ra0, sA0, sgn, c);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) sb.template park_chunk<false>(rb0, sB0, 1.0f, c);
+        tile_of(t_begin + 1, oa, ob, sgn);
+#pragma unroll
+        for (int c = 0; c < NA; ++c) sa.load_chunk(ra1, oa, c);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) sb.load_chunk(rb1, ob, c);
         __syncthreads();
+        fetch_frags<BM, A_KM, TM>(sA0, wm * WM, 0, lane, fa0);
+        fetch_frags<BN, B_KM, TN>(sB0, wn * WN, 0, lane, fb0);
         KURBM_STAMP(ts1);
-        for (int i = 0; i < nt; ++i) {
-            const int cur = i & 1;
-            const bool more = i + 1 < nt;
-            KURBM_STAMP(tsa);
-            // fetch tile i+1 into registers now; it is parked in the other LDS buffer after the
-            // MFMAs of tile i, so its latency hides behind them and one register set suffices
-            if (more) issue(t_begin + i + 1);
-            KURBM_STAMP(tsb);
-            const float* cA = sA0 + cur * A_FL;
-            const float* cB = sB0 + cur * B_FL;
+        // steady state, unrolled by two so the register sets and LDS buffers alternate statically
+        int i = 0;
+        for (; i + 1 < nt; i += 2) {
+            pipelined_tile(i, 0, ra0, rb0, ra1, rb1);
+            pipelined_tile(i + 1, 1, ra1, rb1, ra0, rb0);
+        }
+        if (i < nt) pipelined_tile(i, 0, ra0, rb0, ra1, rb1);
+    }
+    if (do_tail) {
+        // the partial k-tile of each segment: masked, unpipelined (at most two tiles per launch)
+        for (int seg = 0; seg < g.nseg; ++seg) {
+            const int k0 = nfull * BK;
+            const float sgn = seg ? -1.0f : 1.0f;
+            __syncthreads();
+            sa.load_masked(ra0, seg ? g.A1 : g.A0, g.lda, m0, g.M, k0, g.K);
+            sb.load_masked(rb0, seg ? g.B1 : g.B0, g.ldb, n0, g.N, k0, g.K);
+            sa.park_masked(ra0, sA0, m0, g.M, k0, g.K, sgn);
+            sb.park_masked(rb0, sB0, n0, g.N, k0, g.K, 1.0f);
+            __syncthreads();
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                f32x4 fa[TM], fb[TN];
-                fetch_frags<BM, A_KM, TM>(cA, wm * WM, r, lane, fa);
-                fetch_frags<BN, B_KM, TN>(cB, wn * WN, r, lane, fb);
+                fetch_frags<BM, A_KM, TM>(sA0, wm * WM, r, lane, fa1);
+                fetch_frags<BN, B_KM, TN>(sB0, wn * WN, r, lane, fb1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < TN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi][e], fb[ni][e], acc[mi][ni], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) mfma_group(fa1, fb1, e);
             }
-            KURBM_STAMP(tsc);
-            if (more) commit(t_begin + i + 1, cur ^ 1);
-            KURBM_STAMP(tsd);
-            __syncthreads();
-#ifdef KURBM_STAMPS
-            {
-                unsigned long long tse;
-                KURBM_STAMP(tse);
-                seg_issue += tsb - tsa; seg_mfma += tsc - tsb; seg_commit += tsd - tsc; seg_bar += tse - tsd;
-            }
-#endif
         }
     }
+    __syncthreads();   // LDS is reused by the epilogues
     KURBM_STAMP(ts2);
 #ifdef KURBM_STAMPS
 #define KURBM_STAMP_OUT()                                                                        \
@@ -351,8 +410,8 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
         KURBM_STAMP(ts3);                                                                        \
         if (g.stamps && lane == 0) {                                                             \
             unsigned long long* o = g.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;              \
-            o[0] = ts1 - ts0; o[1] = ts2 - ts1; o[2] = ts3 - ts2; o[3] = seg_issue;              \
-            o[4] = seg_mfma; o[5] = seg_commit; o[6] = seg_bar; o[7] = ts0;                      \
+            o[0] = ts1 - ts0; o[1] = ts2 - ts1; o[2] = ts3 - ts2; o[3] = 0;                      \
+            o[4] = 0; o[5] = 0; o[6] = 0; o[7] = ts0;                                            \
         }                                                                                        \
     } while (0)
 #else
