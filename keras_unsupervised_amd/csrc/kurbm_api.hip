@@ -458,6 +458,7 @@ int kurbm_outer_delta(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, co
 #ifdef KURBM_STAMPS
 /* diagnostic library only: not part of include/kurbm.h */
 void kurbm_debug_set_stamp_buffer(void* p) { set_stamp_buffer(static_cast<unsigned long long*>(p)); }
+void kurbm_debug_set_off(int mask) { set_debug_off(mask); }
 #endif
 
 }  // extern "C"

@@ -53,12 +53,14 @@ struct GemmArgs {
     // softplus epilogue
     float* rowpart;     // [grid_n][ld_rowpart]
     int ld_rowpart;
-    // diagnostic build only (KURBM_STAMPS): 8 x u64 per wave
+    // diagnostic build only (KURBM_STAMPS): 16 x u64 per wave
     unsigned long long* stamps;
+    int dbg_off;        // ablation mask: 1 fetches, 2 parks, 4 fragment reads, 8 barrier (results are garbage)
 };
 
 // Diagnostic hook: the next GEMM launches write their s_memtime stamps here (null = off).
 void set_stamp_buffer(unsigned long long* p);
+void set_debug_off(int mask);
 
 struct ReduceArgs {
     const float* slab;

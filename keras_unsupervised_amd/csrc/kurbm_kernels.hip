@@ -36,7 +36,7 @@
 namespace kurbm {
 
 // Diagnostic build only (-DKURBM_STAMPS, libkurbm_stamps.so): s_memtime brackets around the
-// segments of the k loop, written to GemmArgs::stamps.  The shipped library has no stamps.
+// prologue / k loop / epilogue and the 8 MFMA groups of a tile, written to GemmArgs::stamps (16 x u64 per wave).  The shipped library has no stamps.
 #ifdef KURBM_STAMPS
 #define KURBM_STAMP(var)                                                                        \
     do {                                                                                        \
@@ -44,8 +44,10 @@ namespace kurbm {
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");             \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     } while (0)
+#define KURBM_ON(bit) (!(g.dbg_off & (bit)))   /* ablation switches of the diagnostic build */
 #else
 #define KURBM_STAMP(var) do { } while (0)
+#define KURBM_ON(bit) true
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -269,16 +271,19 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
     StB sb;
     sa.init(g.lda, m0, g.M, tid);
     sb.init(g.ldb, n0, g.N, tid);
-    typename StA::Regs ra0, ra1;   // two tiles in flight: one being parked, one being fetched
-    typename StB::Regs rb0, rb1;
+    typename StA::Regs ra;   // the tile in flight between global memory and LDS
+    typename StB::Regs rb;
     float* sA0 = smem;
     float* sB0 = smem + 2 * A_FL;
     constexpr bool SIGNED = (EPI == EPI_SLAB);   // only the statistics GEMM has a negative segment
     constexpr int NA = StA::ITERS, NB = StB::ITERS, NCH = NA + NB;
-    static_assert(NCH <= 8, "one fetch per MFMA group");
+    static_assert(NCH <= 8, "at most two fetches per MFMA group");
 
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
     (void)ts0; (void)ts1; (void)ts2; (void)ts3;
+#ifdef KURBM_STAMPS
+    unsigned long long seg_grp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     KURBM_STAMP(ts0);
 
     // full tile t (clamped to the slice) -> operand origins and sign
@@ -298,89 +303,93 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi][e], fb[ni][e], acc[mi][ni], 0, 0, 0);
     };
 
-    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];   // fragments: k 0..15 and k 16..31 of the current tile
-    f32x4 na0[TM], nb0[TN];                     // k 0..15 of the next tile (prefetched)
-
-    // One k-tile, software pipelined over its 8 MFMA groups (group = one of the 8 k-steps of 4):
-    //   * tile i+2 is fetched from global memory, one 16-B chunk per group        (regs L)
-    //   * tile i+1, fetched during the previous tile, is parked in the other LDS
-    //     buffer during groups 0..5                                                (regs P)
-    //   * ONE barrier per tile, after group 5: by then every wave has read all its fragments
-    //     of the current buffer (k 16..31 are read in group 1) and written its share of the
-    //     next one, so groups 6-7 can already prefetch the next tile's first fragments.
-    // sched_barrier(0) pins this order; inside a group hipcc schedules freely.
-    auto pipelined_tile = [&](int i, int cur, typename StA::Regs& LA, typename StB::Regs& LB,
-                              const typename StA::Regs& PA, const typename StB::Regs& PB) {
-        const float *oa, *ob, *pa_, *pb_;
-        float sgn_l, sgn_p;
-        tile_of(t_begin + i + 2, oa, ob, sgn_l);
-        tile_of(t_begin + i + 1, pa_, pb_, sgn_p);
-        (void)sgn_l; (void)pa_; (void)pb_;
-        const float* cA = sA0 + cur * A_FL;
-        const float* cB = sB0 + cur * B_FL;
-        float* nA = sA0 + (cur ^ 1) * A_FL;
-        float* nB = sB0 + (cur ^ 1) * B_FL;
-#pragma unroll
-        for (int grp = 0; grp < 8; ++grp) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (grp < NCH) {   // fetch chunk `grp` of tile i+2
-                if (grp < NA) sa.load_chunk(LA, oa, grp);
-                else sb.load_chunk(LB, ob, grp - NA);
-            }
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)   // park the chunks of tile i+1 assigned to this group
-                if ((c * 6) / NCH == grp) {
-                    if (c < NA) sa.template park_chunk<SIGNED>(PA, nA, sgn_p, c);
-                    else sb.template park_chunk<false>(PB, nB, 1.0f, c - NA);
-                }
-            if (grp == 1) {
-                fetch_frags<BM, A_KM, TM>(cA, wm * WM, 1, lane, fa1);
-                fetch_frags<BN, B_KM, TN>(cB, wn * WN, 1, lane, fb1);
-            }
-            if (grp == 6) {
-                fetch_frags<BM, A_KM, TM>(nA, wm * WM, 0, lane, na0);
-                fetch_frags<BN, B_KM, TN>(nB, wn * WN, 0, lane, nb0);
-            }
-            if (grp < 4) mfma_group(fa0, fb0, grp);
-            else mfma_group(fa1, fb1, grp - 4);
-            if (grp == 5) __syncthreads();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < TM; ++q) fa0[q] = na0[q];
-#pragma unroll
-        for (int q = 0; q < TN; ++q) fb0[q] = nb0[q];
-    };
+    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];   // fragments of the current tile: k 0..15 and k 16..31
 
     if (nt > 0) {
-        // fill: tile 0 -> LDS buffer 0, tile 1 -> registers (set 1), first fragments of tile 0
+        // fill: tile 0 -> LDS buffer 0, then its first fragments
         const float *oa, *ob;
         float sgn;
         tile_of(t_begin, oa, ob, sgn);
 #pragma unroll
-        for (int c = 0; c < NA; ++c) sa.load_chunk(ra0, oa, c);
+        for (int c = 0; c < NA; ++c) sa.load_chunk(ra, oa, c);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) sb.load_chunk(rb0, ob, c);
+        for (int c = 0; c < NB; ++c) sb.load_chunk(rb, ob, c);
 #pragma unroll
-        for (int c = 0; c < NA; ++c) sa.template park_chunk<SIGNED>(ra0, sA0, sgn, c);
+        for (int c = 0; c < NA; ++c) sa.template park_chunk<SIGNED>(ra, sA0, sgn, c);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) sb.template park_chunk<false>(rb0, sB0, 1.0f, c);
-        tile_of(t_begin + 1, oa, ob, sgn);
-#pragma unroll
-        for (int c = 0; c < NA; ++c) sa.load_chunk(ra1, oa, c);
-#pragma unroll
-        for (int c = 0; c < NB; ++c) sb.load_chunk(rb1, ob, c);
+        for (int c = 0; c < NB; ++c) sb.template park_chunk<false>(rb, sB0, 1.0f, c);
         __syncthreads();
         fetch_frags<BM, A_KM, TM>(sA0, wm * WM, 0, lane, fa0);
         fetch_frags<BN, B_KM, TN>(sB0, wn * WN, 0, lane, fb0);
         KURBM_STAMP(ts1);
-        // steady state, unrolled by two so the register sets and LDS buffers alternate statically
+
+        // One k-tile = 8 MFMA groups (one per k-step of 4), software pipelined:
+        //   groups 0-3  fetch tile i+1 from global memory into registers (two 16-B chunks per group)
+        //               and, in group 1, read the k 16..31 fragments of the current LDS buffer
+        //   groups 4-6  park tile i+1 in the other LDS buffer (its loads are >= 3 groups old)
+        //   end of 6    the tile's ONLY barrier: every wave has read all its fragments of the current
+        //               buffer and written its share of the next one
+        //   group 7     read the next tile's k 0..15 fragments (fa0/fb0 are dead since group 3)
+        // sched_barrier(0) pins this order; inside a group hipcc schedules freely.  Past the end of
+        // the slice the loop re-fetches / re-parks the last tile (in bounds, never read), so the
+        // body is branch-free.
+        int t_fetch = t_begin + 1;            // the tile fetched (and parked) during the current one
+        tile_of(t_fetch, oa, ob, sgn);
+        auto one_tile = [&](const int cur) {  // cur is a literal at both call sites: LDS offsets fold
+            const float* cA = sA0 + cur * A_FL;
+            const float* cB = sB0 + cur * B_FL;
+            float* nA = sA0 + (cur ^ 1) * A_FL;
+            float* nB = sB0 + (cur ^ 1) * B_FL;
+#ifdef KURBM_STAMPS
+            unsigned long long tg[9];
+#endif
+#pragma unroll
+            for (int grp = 0; grp < 8; ++grp) {
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef KURBM_STAMPS
+                KURBM_STAMP(tg[grp]);
+#endif
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c / 2 == grp && KURBM_ON(1)) {           // fetch
+                        if (c < NA) sa.load_chunk(ra, oa, c);
+                        else sb.load_chunk(rb, ob, c - NA);
+                    }
+                    if (4 + (c * 3) / NCH == grp && KURBM_ON(2)) {   // park, 3+ groups after the fetch
+                        if (c < NA) sa.template park_chunk<SIGNED>(ra, nA, sgn, c);
+                        else sb.template park_chunk<false>(rb, nB, 1.0f, c - NA);
+                    }
+                }
+                if (grp == 1 && KURBM_ON(4)) {
+                    fetch_frags<BM, A_KM, TM>(cA, wm * WM, 1, lane, fa1);
+                    fetch_frags<BN, B_KM, TN>(cB, wn * WN, 1, lane, fb1);
+                }
+                if (grp == 7) {
+                    if (KURBM_ON(4)) {
+                        fetch_frags<BM, A_KM, TM>(nA, wm * WM, 0, lane, fa0);
+                        fetch_frags<BN, B_KM, TN>(nB, wn * WN, 0, lane, fb0);
+                    }
+                    // scalar bookkeeping for the NEXT tile's fetches rides under this group's MFMAs
+                    ++t_fetch;
+                    tile_of(t_fetch, oa, ob, sgn);
+                }
+                if (grp < 4) mfma_group(fa0, fb0, grp);
+                else mfma_group(fa1, fb1, grp - 4);
+                if (grp == 6 && KURBM_ON(8)) __syncthreads();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef KURBM_STAMPS
+            KURBM_STAMP(tg[8]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) seg_grp[q] += tg[q + 1] - tg[q];
+#endif
+        };
         int i = 0;
         for (; i + 1 < nt; i += 2) {
-            pipelined_tile(i, 0, ra0, rb0, ra1, rb1);
-            pipelined_tile(i + 1, 1, ra1, rb1, ra0, rb0);
+            one_tile(0);
+            one_tile(1);
         }
-        if (i < nt) pipelined_tile(i, 0, ra0, rb0, ra1, rb1);
+        if (i < nt) one_tile(0);
     }
     if (do_tail) {
         // the partial k-tile of each segment: masked, unpipelined (at most two tiles per launch)
@@ -388,13 +397,14 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
             const int k0 = nfull * BK;
             const float sgn = seg ? -1.0f : 1.0f;
             __syncthreads();
-            sa.load_masked(ra0, seg ? g.A1 : g.A0, g.lda, m0, g.M, k0, g.K);
-            sb.load_masked(rb0, seg ? g.B1 : g.B0, g.ldb, n0, g.N, k0, g.K);
-            sa.park_masked(ra0, sA0, m0, g.M, k0, g.K, sgn);
-            sb.park_masked(rb0, sB0, n0, g.N, k0, g.K, 1.0f);
+            sa.load_masked(ra, seg ? g.A1 : g.A0, g.lda, m0, g.M, k0, g.K);
+            sb.load_masked(rb, seg ? g.B1 : g.B0, g.ldb, n0, g.N, k0, g.K);
+            sa.park_masked(ra, sA0, m0, g.M, k0, g.K, sgn);
+            sb.park_masked(rb, sB0, n0, g.N, k0, g.K, 1.0f);
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
+                if (r == 1 && g.K - k0 <= 16) break;   // k 16..31 of the tile are all padding
                 fetch_frags<BM, A_KM, TM>(sA0, wm * WM, r, lane, fa1);
                 fetch_frags<BN, B_KM, TN>(sB0, wn * WN, r, lane, fb1);
 #pragma unroll
@@ -409,9 +419,9 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
     do {                                                                                         \
         KURBM_STAMP(ts3);                                                                        \
         if (g.stamps && lane == 0) {                                                             \
-            unsigned long long* o = g.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;              \
-            o[0] = ts1 - ts0; o[1] = ts2 - ts1; o[2] = ts3 - ts2; o[3] = 0;                      \
-            o[4] = 0; o[5] = 0; o[6] = 0; o[7] = ts0;                                            \
+            unsigned long long* o = g.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;             \
+            o[0] = ts1 - ts0; o[1] = ts2 - ts1; o[2] = ts3 - ts2; o[3] = ts0;                    \
+            for (int q = 0; q < 8; ++q) o[4 + q] = seg_grp[q];                                   \
         }                                                                                        \
     } while (0)
 #else
@@ -685,11 +695,14 @@ void tile_shape(int cfg, int* bm, int* bn) {
 }
 
 static unsigned long long* g_stamp_buffer = nullptr;
+static int g_dbg_off = 0;
 void set_stamp_buffer(unsigned long long* p) { g_stamp_buffer = p; }
+void set_debug_off(int mask) { g_dbg_off = mask; }
 
 hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g_in, hipStream_t st) {
     GemmArgs g = g_in;
     g.stamps = g_stamp_buffer;
+    g.dbg_off = g_dbg_off;
 #define KURBM_CASE(L, AK, BKM, E, NZ)                                                               \
     if (layout == L && epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) {                          \
         switch (cfg) {                                                                              \

@@ -31,32 +31,36 @@ V = DeviceMatrix.from_host((g.random((B, NV)) < 0.19).astype(np.float32), dev)
 lib = eng.lib
 lib.kurbm_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 lib.kurbm_debug_set_stamp_buffer.restype = None
-buf = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+lib.kurbm_debug_set_off.argtypes = [C.c_int]
+lib.kurbm_debug_set_off.restype = None
+OFF = int(os.environ.get("STAMP_OFF", "0"))   # ablation mask: 1 fetches, 2 parks, 4 fragment reads, 8 barrier
+buf = torch.zeros(4096 * 16, dtype=torch.int64, device=dev)
 
 
-def run(name, fn, nblocks):
+def run(name, fn, nblocks, ntiles):
     for _ in range(3):
         fn()
     buf.zero_()
     lib.kurbm_debug_set_stamp_buffer(buf.data_ptr())
+    lib.kurbm_debug_set_off(OFF)
     fn()
     torch.cuda.synchronize()
     lib.kurbm_debug_set_stamp_buffer(None)
-    s = buf.cpu().numpy().reshape(-1, 8)[: nblocks * 4].astype(np.float64)
+    lib.kurbm_debug_set_off(0)
+    s = buf.cpu().numpy().reshape(-1, 16)[: nblocks * 4].astype(np.float64)
     s = s[s[:, 1] > 0]
     med = np.median(s, axis=0)
     tot = med[0] + med[1] + med[2]
-    span = (s[:, 7].max() - s[:, 7].min())
-    print("%-22s waves=%4d  total %7.0f cyc | prologue %5.1f%%  loop %5.1f%%  epilogue %5.1f%% | in loop: issue %4.1f%%  "
-          "mfma %4.1f%%  park %4.1f%%  barrier %4.1f%% | start skew %.0f cyc"
-          % (name, len(s), tot, 100 * med[0] / tot, 100 * med[1] / tot, 100 * med[2] / tot, 100 * med[3] / med[1],
-             100 * med[4] / med[1], 100 * med[5] / med[1], 100 * med[6] / med[1], span))
+    grp = med[4:12]
+    print("off=%2d %-20s waves=%4d total %7.0f cyc | prologue %4.1f%% loop %4.1f%% epilogue %4.1f%% | loop cycles per tile by MFMA group: %s (sum %.0f)"
+          % (OFF, name, len(s), tot, 100 * med[0] / tot, 100 * med[1] / tot, 100 * med[2] / tot,
+             " ".join("%4.0f" % (x / ntiles) for x in grp), grp.sum() / ntiles))
 
 
 h_pos = eng.half_step("vh", V, B, 0, 0, 1, 42, 0, 0)["sample"]
 v_neg = eng.half_step("hv", h_pos, B, 0, 0, 1, 42, 1, 0)["sample"]
 h_neg = eng.half_step("vh", v_neg, B, 0, 0, 0, 42, 0, 0, want_sample=False, want_prob=True)["prob"]
-run("half_step_vh_sample", lambda: eng.half_step("vh", V, B, 0, 0, 1, 42, 0, 0), 256)
-run("half_step_hv_sample", lambda: eng.half_step("hv", h_pos, B, 0, 0, 1, 42, 1, 0), 224)
-run("half_step_vh_prob", lambda: eng.half_step("vh", v_neg, B, 0, 0, 0, 42, 0, 0, want_sample=False, want_prob=True), 256)
-run("outer_stats", lambda: eng.outer_delta(V, h_pos, v_neg, h_neg, B), 224)
+run("half_step_vh_sample", lambda: eng.half_step("vh", V, B, 0, 0, 1, 42, 0, 0), 256, 24)
+run("half_step_hv_sample", lambda: eng.half_step("hv", h_pos, B, 0, 0, 1, 42, 1, 0), 224, 32)
+run("half_step_vh_prob", lambda: eng.half_step("vh", v_neg, B, 0, 0, 0, 42, 0, 0, want_sample=False, want_prob=True), 256, 24)
+run("outer_stats", lambda: eng.outer_delta(V, h_pos, v_neg, h_neg, B), 224, 64)
