@@ -154,14 +154,27 @@ def main():
         k_vh = lambda: _lib.check(lib.kurbm_half_step_vh(ctx, P, V.ptr(), BATCH, V.ld, 0, 1, C.byref(rng), o_h.ptr(), None, o_h.ld, st()))
         k_hv = lambda: _lib.check(lib.kurbm_half_step_hv(ctx, P, h_pos.ptr(), BATCH, h_pos.ld, 0, 1, C.byref(rng), o_v.ptr(), None, o_v.ld, st()))
         k_vhp = lambda: _lib.check(lib.kurbm_half_step_vh(ctx, P, v_neg.ptr(), BATCH, v_neg.ld, 0, 0, None, None, o_h.ptr(), o_h.ld, st()))
-        k_out = lambda: _lib.check(lib.kurbm_outer_delta(ctx, V.ptr(), h_pos.ptr(), v_neg.ptr(), h_neg.ptr(), BATCH, N_VIS, N_HID,
-                                                         V.ld, h_pos.ld, dW.data_ptr(), ws.data_ptr(), ws.numel(), st()))
+        k_out = lambda: _lib.check(lib.kurbm_outer_partial(ctx, V.ptr(), h_pos.ptr(), v_neg.ptr(), h_neg.ptr(), BATCH, N_VIS, N_HID,
+                                                           V.ld, h_pos.ld, ws.data_ptr(), ws.numel(), st()))
+        k_outred = lambda: _lib.check(lib.kurbm_outer_delta(ctx, V.ptr(), h_pos.ptr(), v_neg.ptr(), h_neg.ptr(), BATCH, N_VIS, N_HID,
+                                                            V.ld, h_pos.ld, dW.data_ptr(), ws.data_ptr(), ws.numel(), st()))
         kern = {}
         for name, fn, flop in (("half_step_vh_sample", k_vh, FLOP_HALF), ("half_step_hv_sample", k_hv, FLOP_HALF),
-                               ("half_step_vh_prob", k_vhp, FLOP_HALF), ("outer_stats_plus_reduce", k_out, FLOP_OUTER)):
+                               ("half_step_vh_prob", k_vhp, FLOP_HALF), ("outer_stats_gemm", k_out, FLOP_OUTER),
+                               ("outer_stats_gemm_plus_reduce", k_outred, FLOP_OUTER)):
             ms = event_time_ms(fn, 50)
             kern[name] = {"ms": ms, "tflops": flop / (ms * 1e-3) / 1e12, "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
-        dom = max(kern, key=lambda k: kern[k]["ms"])
+        dom = max((k for k in kern if k != "outer_stats_gemm_plus_reduce"), key=lambda k: kern[k]["ms"])
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+        # (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE; profiles/*_hbm_traffic.json)
+        traffic = None
+        try:
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+            if tf:
+                traffic = json.load(open(tf[-1])).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
         step_tflops = FLOP_STEP / (ms_per_step * 1e-3) / 1e12
         out = {
             "metric": "cd1_gibbs_steps_per_sec", "value": value,
@@ -173,7 +186,7 @@ def main():
                        "cd_k": 1, "update_mode": "fused", "lr": "1e-3/4096", "parallelism": "dp%d" % world,
                        "flop_per_step": FLOP_STEP},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": kern[dom]["frac"], "traffic": None,
+                         "unit": "TFLOP/s", "frac": kern[dom]["frac"], "traffic": traffic,
                          "kernels": kern, "step_tflops": step_tflops * world, "step_frac": step_tflops / PEAK_F32_MFMA_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:

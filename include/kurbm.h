@@ -175,6 +175,15 @@ int kurbm_outer_delta(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, co
                       float* delta_w, void* workspace, size_t workspace_bytes,
                       kurbm_stream_t stream);
 
+/*
+ * The split-K slab GEMM of kurbm_outer_delta WITHOUT the slab reduction (measurement hook: this
+ * is the dominant kernel of a CD step, timed alone for the roofline line of bench.py).  The
+ * partial sums stay in `workspace`.
+ */
+int kurbm_outer_partial(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, const float* v_neg,
+                        const float* h_neg, int rows, int n_vis, int n_hid, int ldv, int ldh,
+                        void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

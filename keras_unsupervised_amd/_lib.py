@@ -55,6 +55,7 @@ SIGNATURES = {
     "kurbm_apply_delta": (_i, [_vp, _PP, _vp, C.c_float, _i, _vp]),
     "kurbm_free_energy": (_i, [_vp, _PP, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "kurbm_outer_delta": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "kurbm_outer_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 _lib = None

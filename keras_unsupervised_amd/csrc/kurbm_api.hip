@@ -71,25 +71,23 @@ static RngArgs make_rng(uint64_t seed, uint64_t row0, uint32_t stream_id, uint32
 }
 
 // ---- planning -------------------------------------------------------------------------
-// cost of covering an M x N output with one configuration: full waves of workgroups over the
-// CUs times the tile area (every workgroup runs the same k extent).
+// Tile choice for an M x N output.  Model, fitted to MI355X measurements of this kernel family
+// (profiles/): time ~ padded MFMA work x CU imbalance / efficiency, where a CU that holds
+// two or more workgroups (their barriers and epilogues interleave) runs ~0.70 MFMA-busy and a CU
+// with a single workgroup ~0.62.  Ties go to the larger tile (less L2 -> LDS traffic).
 static int pick_cfg(int ncu, int M, int N, int* gm_out, int* gn_out, int force = -1) {
-    if (force >= 0 && force < CFG_COUNT) {
-        int bm, bn;
-        tile_shape(force, &bm, &bn);
-        *gm_out = ceil_div(M, bm);
-        *gn_out = ceil_div(N, bn);
-        return force;
-    }
     int best = 0;
-    long long best_cost = -1, best_blocks = 0;
-    for (int c = 0; c < 3; ++c) {   // automatic choice among the one-wave-per-SIMD tiles
+    double best_cost = -1.0;
+    long long best_blocks = 0;
+    for (int c = 0; c < CFG_COUNT; ++c) {
+        if (force >= 0 && force < CFG_COUNT && c != force) continue;
         int bm, bn;
         tile_shape(c, &bm, &bn);
         const long long blocks = (long long)ceil_div(M, bm) * ceil_div(N, bn);
-        const long long waves = (blocks + ncu - 1) / ncu;
-        const long long cost = waves * bm * bn;
-        if (best_cost < 0 || cost < best_cost || (cost == best_cost && blocks < best_blocks)) {
+        const long long per_cu = (blocks + ncu - 1) / ncu;                 // what the busiest CU runs
+        const double eff = (blocks >= 2LL * ncu) ? 0.70 : (blocks > ncu ? 0.66 : 0.62);
+        const double cost = (double)per_cu * bm * bn / eff;
+        if (best_cost < 0 || cost < best_cost * 0.999 || (cost <= best_cost * 1.001 && blocks < best_blocks)) {
             best = c; best_cost = cost; best_blocks = blocks;
         }
     }
@@ -120,7 +118,8 @@ static OuterPlan plan_outer(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid
     pl.nkt = rows / 32;          // full k-tiles per segment; a rows % 32 tail goes to the last slice
     pl.kt_total = 2 * pl.nkt;
     const int tiles = pl.gm * pl.gn;
-    int s = ctx->force_split > 0 ? ctx->force_split : ncu / tiles;
+    // two workgroups per CU: their barriers / slab stores interleave (measured 8-10 % over one per CU)
+    int s = ctx->force_split > 0 ? ctx->force_split : (2 * ncu) / tiles;
     if (s < 1) s = 1;
     if (s > pl.kt_total) s = pl.kt_total;
     if (s < 1) s = 1;
@@ -453,6 +452,23 @@ int kurbm_outer_delta(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, co
     // no bias work: n_hid/n_vis bias blocks see null partial pointers and do nothing
     HIP_TRY(launch_reduce_apply(a, st));
     return KURBM_OK;
+}
+
+int kurbm_outer_partial(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, const float* v_neg, const float* h_neg,
+                        int rows, int n_vis, int n_hid, int ldv, int ldh, void* workspace, size_t workspace_bytes,
+                        kurbm_stream_t stream) {
+    if (!ctx) return fail(KURBM_ERR_ARG, "null argument");
+    if (rows <= 0 || n_vis <= 0 || n_hid <= 0) return fail(KURBM_ERR_ARG, "bad shape");
+    if (bad_matrix(v_pos, ldv, n_vis) || bad_matrix(v_neg, ldv, n_vis) || bad_matrix(h_pos, ldh, n_hid) ||
+        bad_matrix(h_neg, ldh, n_hid))
+        return fail(KURBM_ERR_ARG, "operand: null, misaligned, ld %% 4 != 0 or ld < columns");
+    if (!workspace || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "workspace is null or misaligned");
+    const Workspace w = carve(ctx, workspace, rows, n_vis, n_hid, 1);
+    if (w.bytes > workspace_bytes)
+        return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    const OuterPlan pl = plan_outer(ctx, rows, n_vis, n_hid);
+    return outer_slabs(ctx, v_pos, h_pos, v_neg, h_neg, rows, n_vis, n_hid, ldv, ldh, w.slab, w.slab_stride, pl,
+                       static_cast<hipStream_t>(stream));
 }
 
 #ifdef KURBM_STAMPS
