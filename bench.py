@@ -105,9 +105,17 @@ def main():
     lr = 1e-3 / BATCH            # keeps the weights finite over long runs; throughput does not depend on lr
     seed = 42
 
+    # BENCH_FORCE_DP=1 runs the data-parallel sequence (emit delta, all-reduce, apply) even on one
+    # rank: a plumbing rehearsal of the N > 1 path on a single-GPU box
+    force_dp = os.environ.get("BENCH_FORCE_DP", "0") == "1"
+    if force_dp and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+
     def step(i):
         lo = (i % n_batches) * BATCH
-        if world == 1:
+        if world == 1 and not force_dp:
             eng.cd_step(V, BATCH, lo, lr, seed, i)
         else:
             eng.cd_step(V, BATCH, lo, lr, seed, i, apply=False, emit_delta=True, row0=rank * BATCH)
@@ -117,14 +125,14 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -191,7 +199,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:

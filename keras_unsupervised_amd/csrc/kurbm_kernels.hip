@@ -614,15 +614,36 @@ __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
         const long long q = (long long)blockIdx.x * 256 + tid;
         if (q >= (long long)a.n_vis * groups) return;
         const int i = (int)(q / groups), j0 = (int)(q - (long long)i * groups) * 4;
+        // slabs are summed in index order (bit-reproducible); four loads in flight per lane
+        const float* sp = a.slab + (size_t)i * a.ld_slab + j0;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int zz = 0; zz < a.nslab; ++zz)
-            s += *reinterpret_cast<const f32x4*>(a.slab + (size_t)zz * a.slab_stride + (size_t)i * a.ld_slab + j0);
+        int zz = 0;
+        for (; zz + 4 <= a.nslab; zz += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 0) * a.slab_stride);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 1) * a.slab_stride);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 2) * a.slab_stride);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 3) * a.slab_stride);
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; zz < a.nslab; ++zz) s += *reinterpret_cast<const f32x4*>(sp + (size_t)zz * a.slab_stride);
+        if (j0 + 3 < a.n_hid) {   // whole 16-B group inside the matrix: vector read-modify-write
+            if (a.W) {
+                f32x4* w = reinterpret_cast<f32x4*>(a.W + (size_t)i * a.ldw + j0);
+                *w = *w + s * a.lr;
+            }
+            if (a.delta_w) {
+                float* d = a.delta_w + (size_t)i * a.n_hid + j0;
+                if ((a.n_hid & 3) == 0) *reinterpret_cast<f32x4*>(d) = s;
+                else { d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w; }
+            }
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = j0 + e;
-            if (j < a.n_hid) {
-                if (a.delta_w) a.delta_w[(size_t)i * a.n_hid + j] = s[e];
-                if (a.W) a.W[(size_t)i * a.ldw + j] += a.lr * s[e];
+            for (int e = 0; e < 4; ++e) {
+                const int j = j0 + e;
+                if (j < a.n_hid) {
+                    if (a.delta_w) a.delta_w[(size_t)i * a.n_hid + j] = s[e];
+                    if (a.W) a.W[(size_t)i * a.ldw + j] += a.lr * s[e];
+                }
             }
         }
         return;

@@ -35,8 +35,8 @@ def shard_rows(n_rows, world_size, rank):
 
 
 def allreduce_sum_(delta, async_op=False):
-    """In-place sum of the packed delta over all ranks (no-op for one process)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """In-place sum of the packed delta over all ranks (no-op without a process group)."""
+    if dist.is_available() and dist.is_initialized():
         return dist.all_reduce(delta, op=dist.ReduceOp.SUM, async_op=async_op)
     return None
 

@@ -369,3 +369,51 @@ def test_c_abi_error_behaviour(gpu_device):
         e.cd_step(vd, 8, 0, 0.1, 1, 0, k=0)
     with pytest.raises(ValueError):
         e.half_step("hv", vd, 8, 0, 0, 1, 1, 0, 0)      # 16 columns into an 8-wide hidden layer
+
+
+def test_checkpoint_round_trip(gpu_device, tmp_path):
+    """f-4: config + weights (+ RNG counters) survive save/load; the reloaded RBM continues bit-identically."""
+    from keras_unsupervised_amd.ebm import DBN, MODE_VISIBLE_BERNOULLI, RBM, load_dbn, load_rbm, save_dbn, save_rbm
+    nv, nh = 36, 20
+    V = synthetic_binary(50, nv, seed=70, p=0.4)
+    hps = {"batch_size": 16, "epochs": 1, "lr": 0.05}
+    a = RBM(hps, nh, name="ck", mode=MODE_VISIBLE_BERNOULLI, seed=3, cd_k=2, weights=synthetic_params(nv, nh, 71))
+    a.fit(V, verbose=0)
+    save_rbm(a, str(tmp_path / "ck"))
+    b = load_rbm(str(tmp_path / "ck"))
+    assert b.mode == a.mode and b.cd_k == 2 and b.name == "ck" and b.hps == hps
+    for x, y in zip(a.get_weights(), b.get_weights()):
+        assert np.array_equal(x, y)                      # visible bias included (the reference drops it)
+    a.fit(V, verbose=0)
+    b.fit(V, verbose=0)
+    assert np.array_equal(a.rbm_weight, b.rbm_weight)    # same counters -> same draws -> same bits
+    assert np.array_equal(a.transform(V)[0], b.transform(V)[0])
+    d = DBN()
+    d.add_stack(a)
+    d.add_stack(RBM(hps, 8, name="top", mode=MODE_VISIBLE_BERNOULLI, seed=4, weights=synthetic_params(nh, 8, 72)))
+    d.fit(V, verbose=0)
+    save_dbn(d, str(tmp_path / "stack"))
+    d2 = load_dbn(str(tmp_path / "stack"))
+    assert np.array_equal(d.transform(V), d2.transform(V))
+
+
+def test_example_pipeline_digits(gpu_device, tmp_path):
+    """f-3: RBM features -> softmax head on the bundled 8x8 digits (upsampled to 784), end to end."""
+    import importlib.util
+    import json as _json
+    spec = importlib.util.spec_from_file_location("rbm_softmax_digits", os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "rbm", "rbm_softmax_digits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    conf = _json.load(open(os.path.join(os.path.dirname(spec.origin), "rbm_softmax_conf.json")))
+    conf["data"] = "digits"
+    conf["hps"]["epochs"] = 15
+    mc = mod.MNISTClassifier(conf, workdir=str(tmp_path))
+    mc.train(verbose=0)
+    acc = mc.test()
+    assert acc is not None and acc > 0.6, "RBM features + softmax should beat chance (0.1) by far, got %r" % acc
+    lines = open(tmp_path / "solution.csv").read().splitlines()
+    assert lines[0] == "ImageId,Label" and len(lines) == 1 + 360
+    conf["model_loading"] = True
+    again = mod.MNISTClassifier(conf, workdir=str(tmp_path))
+    assert np.array_equal(again.rbm.rbm_weight, mc.rbm.rbm_weight)
