@@ -184,6 +184,31 @@ int kurbm_outer_partial(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, 
                         const float* h_neg, int rows, int n_vis, int n_hid, int ldv, int ldh,
                         void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
 
+/* ---- bf16 storage / fp32 accumulate (extension; BASELINE.json config 5) --------------------
+ *
+ * The fp32 parameters of kurbm_params stay authoritative.  A MIRROR buffer (caller-owned device
+ * memory, kurbm_bf16_mirror_bytes) holds their bf16 images in both orientations; it must be
+ * refreshed (kurbm_bf16_mirror_refresh) whenever the caller writes the fp32 weights, and is kept in
+ * sync by kurbm_cd_step_bf16 itself.  Inputs and outputs of these entry points are fp32 exactly as in
+ * the fp32 API; only the matrix products run on bf16 operands (weights, data and probabilities
+ * rounded to nearest even; 0/1 samples are exact), accumulated in fp32.
+ */
+size_t kurbm_bf16_mirror_bytes(kurbm_ctx* ctx, int n_vis, int n_hid);
+int kurbm_bf16_mirror_refresh(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                              kurbm_stream_t stream);
+size_t kurbm_bf16_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int k);
+
+/* Same contract as kurbm_cd_step, products in bf16. */
+int kurbm_cd_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                       const float* v_batch, int rows, int ldv, const kurbm_cd_opts* opts, int which,
+                       void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
+/* One half step with bf16 products (test hook): dir 0 = v->h, 1 = h->v; fp32 in, fp32 planes out. */
+int kurbm_half_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, int dir,
+                         const float* in, int rows, int ld_in, int act, int noise, const kurbm_rng* rng,
+                         float* out_sample, float* out_prob, float* out_u, int ld_out,
+                         void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

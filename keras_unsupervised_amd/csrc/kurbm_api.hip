@@ -478,3 +478,253 @@ void kurbm_debug_set_off(int mask) { set_debug_off(mask); }
 #endif
 
 }  // extern "C"
+
+// ======================================================================================
+// bf16 variant (kurbm_bf16.hip): mirrors, workspace, launch sequences
+// ======================================================================================
+struct Mirror { uint16_t *Wb, *Wtb; int Kh, Kv; size_t bytes; };
+
+static Mirror carve_mirror(void* base, int n_vis, int n_hid) {
+    Mirror m;
+    m.Kh = round_up(n_hid, 128);   // k extent of W  [n_vis][Kh]   (B operand of h->v)
+    m.Kv = round_up(n_vis, 128);   // k extent of Wt [n_hid][Kv]   (B operand of v->h)
+    char* b = static_cast<char*>(base);
+    size_t off = 0;
+    m.Wb = reinterpret_cast<uint16_t*>(b + off);  off = align_up(off + (size_t)n_vis * m.Kh * 2);
+    m.Wtb = reinterpret_cast<uint16_t*>(b + off); off = align_up(off + (size_t)n_hid * m.Kv * 2);
+    m.bytes = off;
+    return m;
+}
+
+struct WorkspaceB {
+    uint16_t *vb, *vbT, *hb, *hbT, *v2b, *v2bT, *h2b, *hnT, *cb;
+    float *part_h, *part_v, *slab, *tmp32;
+    int Kv, Kh, Kb, ldh32, ldv32, max_row_tiles;
+    size_t slab_stride, bytes;
+};
+
+struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_split, ld_slab; };
+
+static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid) {
+    OuterPlanB pl;
+    pl.gm = ceil_div(n_vis, 128);
+    pl.gn = ceil_div(n_hid, 128);
+    pl.nkt = round_up(rows, 128) / 128;
+    pl.kt_total = 2 * pl.nkt;
+    int s = (2 * ctx->ncu) / (pl.gm * pl.gn);
+    if (s < 1) s = 1;
+    if (s > pl.kt_total) s = pl.kt_total;
+    pl.nsplit_bound = s;
+    pl.kt_per_split = ceil_div(pl.kt_total, s);
+    pl.nsplit = ceil_div(pl.kt_total, pl.kt_per_split);
+    pl.ld_slab = round_up(n_hid, 4);
+    return pl;
+}
+
+static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_vis, int n_hid) {
+    WorkspaceB w;
+    w.Kv = round_up(n_vis, 128);
+    w.Kh = round_up(n_hid, 128);
+    w.Kb = round_up(rows, 128);
+    w.ldh32 = round_up(n_hid, 4);
+    w.ldv32 = round_up(n_vis, 4);
+    w.max_row_tiles = ceil_div(rows, 128);
+    const OuterPlanB pl = plan_outer_bf16(ctx, rows, n_vis, n_hid);
+    w.slab_stride = (size_t)n_vis * pl.ld_slab;
+    char* b = static_cast<char*>(base);
+    size_t off = 0;
+    auto take16 = [&](size_t n) { uint16_t* p = reinterpret_cast<uint16_t*>(b + off); off = align_up(off + n * 2); return p; };
+    auto take32 = [&](size_t n) { float* p = reinterpret_cast<float*>(b + off); off = align_up(off + n * 4); return p; };
+    w.vb = take16((size_t)w.Kb * w.Kv);    w.vbT = take16((size_t)n_vis * w.Kb);     // v_pos, both orientations
+    w.hb = take16((size_t)w.Kb * w.Kh);    w.hbT = take16((size_t)n_hid * w.Kb);     // h_pos
+    w.v2b = take16((size_t)w.Kb * w.Kv);   w.v2bT = take16((size_t)n_vis * w.Kb);    // v_t / v_neg
+    w.h2b = take16((size_t)w.Kb * w.Kh);                                             // h_t (k > 1, chain start)
+    w.hnT = take16((size_t)n_hid * w.Kb);                                            // h_neg probabilities, transposed
+    w.cb = take16((size_t)w.Kb * w.Kv);                                              // persistent chain as bf16
+    w.part_h = take32((size_t)w.max_row_tiles * w.ldh32);
+    w.part_v = take32((size_t)w.max_row_tiles * w.ldv32);
+    w.slab = take32(w.slab_stride * pl.nsplit_bound);
+    w.tmp32 = take32((size_t)rows * (w.ldh32 > w.ldv32 ? w.ldh32 : w.ldv32));       // fp32 plane for the test hook
+    w.bytes = off;
+    return w;
+}
+
+// one bf16 half step: A [rows][lda] bf16 (k padded), weights from the mirror
+static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const Mirror& m, const uint16_t* A, int lda,
+                       int rows, int act, int noise, const RngArgs* rng, uint16_t* out, int ldo, uint16_t* outT, int ldoT,
+                       float* out_f32, float* prob_f32, float* out_u, int ldo32, const float* ref32, int ldref32,
+                       const uint16_t* ref16, int ldref16, float* colpart, int ld_colpart, int* grid_m_out, hipStream_t st) {
+    GemmArgsB g;
+    memset(&g, 0, sizeof g);
+    const bool vh = (layout == LAYOUT_VH);
+    g.A0 = A; g.lda = lda;
+    g.B0 = vh ? m.Wtb : m.Wb; g.ldb = vh ? m.Kv : m.Kh;
+    g.M = rows; g.N = vh ? p->n_hid : p->n_vis; g.K = vh ? m.Kv : m.Kh;
+    g.nseg = 1; g.nkt = g.K / 128; g.kt_total = g.nkt; g.kt_per_split = g.nkt; g.nsplit = 1;
+    g.grid_m = ceil_div(rows, 128); g.grid_n = ceil_div(g.N, 128);
+    g.bias = vh ? p->b_h : p->b_v;
+    g.act = act; g.noise = noise;
+    if (rng) g.rng = *rng;
+    g.out = out; g.ldo = ldo; g.ldo_cols = out ? ldo : g.N;
+    g.outT = outT; g.ldoT = ldoT;
+    g.out_f32 = out_f32; g.prob_f32 = prob_f32; g.out_u = out_u; g.ldo32 = ldo32;
+    g.ref32 = ref32; g.ldref32 = ldref32; g.ref16 = ref16; g.ldref16 = ldref16;
+    g.colpart = colpart; g.ld_colpart = ld_colpart;
+    if (grid_m_out) *grid_m_out = g.grid_m;
+    HIP_TRY(launch_gemm_bf16(EPI_HALFSTEP, g, st));
+    return KURBM_OK;
+}
+
+extern "C" {
+
+size_t kurbm_bf16_mirror_bytes(kurbm_ctx* ctx, int n_vis, int n_hid) {
+    if (!ctx || n_vis <= 0 || n_hid <= 0) return 0;
+    return carve_mirror(nullptr, n_vis, n_hid).bytes;
+}
+
+int kurbm_bf16_mirror_refresh(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                              kurbm_stream_t stream) {
+    if (!ctx) return fail(KURBM_ERR_ARG, "ctx is null");
+    if (int e = check_params(p)) return e;
+    if (!mirror || !aligned16(mirror)) return fail(KURBM_ERR_ARG, "mirror is null or misaligned");
+    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid);
+    if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
+    HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.Kh, p->n_vis, m.Wtb, m.Kv, p->n_hid,
+                               static_cast<hipStream_t>(stream)));
+    return KURBM_OK;
+}
+
+size_t kurbm_bf16_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int k) {
+    (void)k;
+    if (!ctx || rows <= 0 || n_vis <= 0 || n_hid <= 0) return 0;
+    return carve_bf16(ctx, nullptr, rows, n_vis, n_hid).bytes;
+}
+
+int kurbm_half_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, int dir,
+                         const float* in, int rows, int ld_in, int act, int noise, const kurbm_rng* rng,
+                         float* out_sample, float* out_prob, float* out_u, int ld_out, void* workspace,
+                         size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx) return fail(KURBM_ERR_ARG, "ctx is null");
+    if (int e = check_params(p)) return e;
+    if (dir != 0 && dir != 1) return fail(KURBM_ERR_ARG, "dir must be 0 (v->h) or 1 (h->v)");
+    const int K = dir == 0 ? p->n_vis : p->n_hid, N = dir == 0 ? p->n_hid : p->n_vis;
+    if (rows <= 0 || bad_matrix(in, ld_in, K)) return fail(KURBM_ERR_ARG, "input: null, misaligned, ld %% 4 != 0 or ld < columns");
+    if (noise != NOISE_NONE && (!rng || (rng->row0 & 3))) return fail(KURBM_ERR_ARG, "rng missing or row0 not a multiple of 4");
+    if (!out_sample && !out_prob) return fail(KURBM_ERR_ARG, "both outputs are null");
+    if (ld_out % 4 != 0 || ld_out < N) return fail(KURBM_ERR_ARG, "ld_out %% 4 != 0 or ld_out < columns");
+    if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid);
+    if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small");
+    const WorkspaceB w = carve_bf16(ctx, workspace, rows, p->n_vis, p->n_hid);
+    if (w.bytes > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    uint16_t* Ab = dir == 0 ? w.vb : w.hb;
+    const int lda = dir == 0 ? w.Kv : w.Kh;
+    HIP_TRY(launch_f32_to_bf16(in, rows, K, ld_in, Ab, lda, w.Kb, nullptr, 0, 0, st));
+    RngArgs r;
+    if (rng) r = make_rng(rng->seed, rng->row0, rng->stream_id, rng->step);
+    float* val = (noise == NOISE_NONE) ? (out_prob ? out_prob : out_sample) : out_sample;
+    float* prob = (noise == NOISE_NONE) ? nullptr : out_prob;
+    return half_step_b(ctx, dir == 0 ? LAYOUT_VH : LAYOUT_HV, p, m, Ab, lda, rows, act, noise, rng ? &r : nullptr, nullptr, 0,
+                       nullptr, 0, val, prob, out_u, ld_out, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, st);
+}
+
+int kurbm_cd_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
+                       int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace, size_t workspace_bytes,
+                       kurbm_stream_t stream) {
+    if (!ctx || !o) return fail(KURBM_ERR_ARG, "null argument");
+    if (int e = check_params(p)) return e;
+    if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
+    if (bad_matrix(v_batch, ldv, p->n_vis)) return fail(KURBM_ERR_ARG, "v_batch: null, misaligned, ld %% 4 != 0 or ld < n_vis");
+    if (o->k < 1 || o->k > 15) return fail(KURBM_ERR_ARG, "k must be in [1, 15]");
+    if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN)
+        return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
+    if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
+    if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
+    if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid);
+    if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
+    const WorkspaceB w = carve_bf16(ctx, workspace, rows, p->n_vis, p->n_hid);
+    if (w.bytes > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+
+    const bool gauss = (o->mode == KURBM_MODE_VISIBLE_GAUSSIAN);
+    const int act_h = gauss ? ACT_RELU : ACT_SIGMOID;
+    const int act_v = gauss ? ACT_LINEAR : ACT_SIGMOID;
+    const int noise_v = gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI;
+    const uint32_t base = o->chain * 64u;
+    const bool need_w = (which & 1) || o->delta_out;
+    int e;
+
+    // v_pos -> bf16, row-major (A of the v->h step) and transposed (statistics)
+    HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Kv, w.Kb, w.vbT, w.Kb, p->n_vis, st));
+    // h_pos ~ p(h | v_pos)                                          rbm.py:120
+    RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
+    if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Kv, rows, act_h, NOISE_BERNOULLI, &r, w.hb, w.Kh, w.hbT, w.Kb, nullptr,
+                         nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, st)))
+        return e;
+    const uint16_t* h_cur = w.hb;
+    if (o->v_chain) {   // persistent chain: negative phase starts from the stored fantasy particles
+        HIP_TRY(launch_f32_to_bf16(o->v_chain, rows, p->n_vis, ldv, w.cb, w.Kv, w.Kb, nullptr, 0, 0, st));
+        r = make_rng(o->seed, o->row0, base + 32u, o->step);
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.cb, w.Kv, rows, act_h, NOISE_BERNOULLI, &r, w.h2b, w.Kh, nullptr, 0, nullptr,
+                             nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, st)))
+            return e;
+        h_cur = w.h2b;
+    }
+    int gm_v = 0, gm_h = 0;
+    for (int t = 1; t <= o->k; ++t) {
+        const bool last = (t == o->k);
+        r = make_rng(o->seed, o->row0, base + 2u * t - 1u, o->step);      // v_t ~ p(v | h_{t-1})   rbm.py:121-123
+        if ((e = half_step_b(ctx, LAYOUT_HV, p, m, h_cur, w.Kh, rows, act_v, noise_v, &r, w.v2b, w.Kv, last ? w.v2bT : nullptr,
+                             w.Kb, (last && o->v_chain) ? o->v_chain : nullptr, nullptr, nullptr, ldv,
+                             last ? v_batch : nullptr, ldv, nullptr, 0, w.part_v, w.ldv32, last ? &gm_v : nullptr, st)))
+            return e;
+        if (!last) {
+            r = make_rng(o->seed, o->row0, base + 2u * t, o->step);
+            if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Kv, rows, act_h, NOISE_BERNOULLI, &r, w.h2b, w.Kh, nullptr, 0,
+                                 nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, st)))
+                return e;
+            h_cur = w.h2b;
+        }
+    }
+    // h_neg = sigmoid(v_neg.W + b_h), probabilities (rbm.py:124): only its transposed image is needed
+    if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Kv, rows, ACT_SIGMOID, NOISE_NONE, nullptr, nullptr, 0, w.hnT, w.Kb, nullptr,
+                         nullptr, nullptr, 0, nullptr, 0, w.hb, w.Kh, w.part_h, w.ldh32, &gm_h, st)))
+        return e;
+
+    // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch
+    const OuterPlanB pl = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid);
+    if (need_w) {
+        GemmArgsB g;
+        memset(&g, 0, sizeof g);
+        g.A0 = w.vbT; g.A1 = w.v2bT; g.lda = w.Kb;
+        g.B0 = w.hbT; g.B1 = w.hnT; g.ldb = w.Kb;
+        g.M = p->n_vis; g.N = p->n_hid; g.K = w.Kb;
+        g.nseg = 2; g.nkt = pl.nkt; g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
+        g.grid_m = pl.gm; g.grid_n = pl.gn;
+        g.slab = w.slab; g.slab_stride = w.slab_stride; g.ld_slab = pl.ld_slab;
+        HIP_TRY(launch_gemm_bf16(EPI_SLAB, g, st));
+    }
+    ReduceArgs a;
+    memset(&a, 0, sizeof a);
+    a.slab = w.slab; a.slab_stride = w.slab_stride; a.nslab = pl.nsplit; a.ld_slab = pl.ld_slab;
+    a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw;
+    a.nblk_w = need_w ? (int)(((long long)p->n_vis * (pl.ld_slab / 4) + 255) / 256) : 0;
+    a.lr = o->lr;
+    const bool ap = o->apply != 0;
+    a.W = (ap && (which & 1)) ? p->W : nullptr;
+    a.delta_w = o->delta_out;
+    a.part_h = w.part_h; a.nrow_tiles_h = gm_h; a.ld_part_h = w.ldh32;
+    a.b_h = (ap && (which & 2)) ? p->b_h : nullptr;
+    a.delta_bh = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid : nullptr;
+    a.part_v = w.part_v; a.nrow_tiles_v = gm_v; a.ld_part_v = w.ldv32;
+    a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
+    a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
+    HIP_TRY(launch_reduce_apply(a, st));
+    if (a.W)   // the fp32 master moved: re-quantise both mirrors
+        HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.Kh, p->n_vis, m.Wtb, m.Kv, p->n_hid, st));
+    return KURBM_OK;
+}
+
+}  // extern "C"

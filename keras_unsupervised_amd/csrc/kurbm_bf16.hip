@@ -1,0 +1,384 @@
+// kurbm_bf16.hip -- bf16-storage / fp32-accumulate variant of the CD kernels (gfx950).
+//
+// BASELINE.json config 5 (4096 x 4096 RBM, bf16, CD-10 persistent chains) is 16x faster on the
+// matrix cores in bf16 (v_mfma_f32_16x16x32_bf16) than the fp32 path, provided every GEMM operand is
+// k-contiguous.  So this variant keeps bf16 MIRRORS in both orientations instead of re-staging:
+//
+//     W  [n_vis][n_hid]  (k = hidden)   -> B operand of the h->v half step
+//     Wt [n_hid][n_vis]  (k = visible)  -> B operand of the v->h half step
+//     activations: row-major [batch][units] (A operand of the next half step) AND transposed
+//     [units][batch] (operands of the statistics GEMM, k = batch), both written by the epilogue
+//
+// Every GEMM is then "NT": A [M][K], B [N][K], one staging layout, one kernel.  All k extents are
+// zero-padded to a multiple of 128 by the host side, so there is no masked tail path.  The fp32
+// master weights stay authoritative: the slab reduction updates them (kurbm_kernels.hip) and the
+// mirrors are re-quantised (round to nearest even) afterwards.
+//
+// Reference op sequences: the same as the fp32 kernels (reference ku/ebm/rbm.py:46-47, :52-53,
+// :121-134); bf16 is an extension of this build, absent from the reference.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kurbm_kernels.h"
+#include "kurbm_device.h"
+
+namespace kurbm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BKB = 128;                 // k-tile in bf16 elements (256 B per row)
+constexpr int ROWB = 2 * BKB + 16;       // LDS row in bytes: +16 B pad -> conflict-free ds_read_b128
+constexpr int NTH = 256;
+
+// ------------------------------------------------------------------------------------
+// fp32 [rows][ld_in] -> bf16 [rows_pad][ldo] (+ transposed bf16 [cols_pad][ldoT]); padding zeroed
+// ------------------------------------------------------------------------------------
+// One 32 x 32 tile per workgroup through LDS; out-of-range source elements read as zero, so the
+// k padding of both mirrors is written here and nowhere else.
+__global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ in, int rows, int cols, int ld_in,
+                                                     uint16_t* __restrict__ out, int ldo, int out_rows,
+                                                     uint16_t* __restrict__ outT, int ldoT, int outT_rows) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        const float v = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : 0.f;
+        tile[ty + 8 * j][tx] = v;
+        if (out && r < out_rows && c < ldo) out[(size_t)r * ldo + c] = (uint16_t)f32_to_bf16_bits(v);
+    }
+    if (!outT) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, r = r0 + tx;   // outT[c][r]
+        if (c < outT_rows && r < ldoT) outT[(size_t)c * ldoT + r] = (uint16_t)f32_to_bf16_bits(tile[tx][ty + 8 * j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// the bf16 NT GEMM
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NOISE>
+__global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int NA = BM * 16 / NTH, NB = BN * 16 / NTH;   // 16-B chunks per lane per tile
+    static_assert((BM * 16) % NTH == 0 && (BN * 16) % NTH == 0, "whole chunks per lane");
+    constexpr int LDE = WN + 4;
+    constexpr int EPI_BYTES = 4 * WM * LDE * 4;
+    constexpr int SMEM_BYTES = (2 * (A_BYTES + B_BYTES) > EPI_BYTES) ? 2 * (A_BYTES + B_BYTES) : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l15 = lane & 15, slot = lane >> 4;
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap (see kurbm_kernels.hip)
+        const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    const int tiles_mn = g.grid_m * g.grid_n;
+    const int z = bid / tiles_mn;
+    const int tmn = bid - z * tiles_mn;
+    const int bm = tmn / g.grid_n, bn = tmn - bm * g.grid_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    const int t_begin = z * g.kt_per_split;
+    int t_end = t_begin + g.kt_per_split;
+    if (t_end > g.kt_total) t_end = g.kt_total;
+    const int nt = t_end > t_begin ? t_end - t_begin : 0;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane staging map: chunk q -> (row q / 16, 16-B chunk q % 16); rows outside the matrix are
+    // pointed at row 0 (they only feed outputs that are never stored)
+    unsigned goffA[NA], goffB[NB];
+    int soffA[NA], soffB[NB];
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+        const int q = it * NTH + tid, row = q >> 4, ch = q & 15;
+        const int x = (m0 + row < g.M) ? m0 + row : 0;
+        goffA[it] = (unsigned)(x * g.lda + 8 * ch);
+        soffA[it] = row * ROWB + 16 * ch;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+        const int q = it * NTH + tid, row = q >> 4, ch = q & 15;
+        const int x = (n0 + row < g.N) ? n0 + row : 0;
+        goffB[it] = (unsigned)(x * g.ldb + 8 * ch);
+        soffB[it] = row * ROWB + 16 * ch;
+    }
+    u32x4 ra[NA], rb[NB];
+    unsigned char* sA0 = smem;
+    unsigned char* sB0 = smem + 2 * A_BYTES;
+    constexpr bool SIGNED = (EPI == EPI_SLAB);
+
+    auto tile_of = [&](int t, const uint16_t*& oa, const uint16_t*& ob, uint32_t& flip) {
+        t = t < t_end ? t : t_end - 1;
+        const int seg = (t >= g.nkt) ? 1 : 0;
+        const size_t k0 = (size_t)(t - seg * g.nkt) * BKB;
+        oa = (seg ? g.A1 : g.A0) + k0;
+        ob = (seg ? g.B1 : g.B0) + k0;
+        flip = seg ? 0x80008000u : 0u;   // sign bits of a bf16 pair: segment 1 enters negated
+    };
+    auto fetch = [&](const uint16_t* oa, const uint16_t* ob) {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) ra[it] = *reinterpret_cast<const u32x4*>(oa + goffA[it]);
+#pragma unroll
+        for (int it = 0; it < NB; ++it) rb[it] = *reinterpret_cast<const u32x4*>(ob + goffB[it]);
+    };
+    auto park = [&](int buf, uint32_t flip) {
+        unsigned char* a = sA0 + buf * A_BYTES;
+        unsigned char* b = sB0 + buf * B_BYTES;
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            u32x4 v = ra[it];
+            if (SIGNED) { v.x ^= flip; v.y ^= flip; v.z ^= flip; v.w ^= flip; }
+            *reinterpret_cast<u32x4*>(a + soffA[it]) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NB; ++it) *reinterpret_cast<u32x4*>(b + soffB[it]) = rb[it];
+    };
+
+    if (nt > 0) {
+        const uint16_t *oa, *ob;
+        uint32_t flip;
+        tile_of(t_begin, oa, ob, flip);
+        fetch(oa, ob);
+        park(0, flip);
+        __syncthreads();
+        // k loop: fetch tile i+1 into registers before the MFMAs of tile i, park it after them.
+        // Branch-free: past the end the last tile is fetched / parked again (in bounds, never read).
+        for (int i = 0; i < nt; ++i) {
+            const int cur = i & 1;
+            tile_of(t_begin + i + 1, oa, ob, flip);
+            fetch(oa, ob);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* cA = sA0 + cur * A_BYTES + (wm * WM + l15) * ROWB + 16 * slot;
+            const unsigned char* cB = sB0 + cur * B_BYTES + (wn * WN + l15) * ROWB + 16 * slot;
+#pragma unroll
+            for (int ks = 0; ks < BKB / 32; ++ks) {
+                u32x4 fa[TM], fb[TN];
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(cA + mi * 16 * ROWB + 64 * ks);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(cB + ni * 16 * ROWB + 64 * ks);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]), acc[mi][ni], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            park(cur ^ 1, flip);
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+
+    // ---------------- epilogue: raw partial sums to a slab (statistics GEMM) ------------
+    if (EPI == EPI_SLAB) {
+        float* slab = g.slab + (size_t)z * g.slab_stride;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int col = n0 + wn * WN + ni * 16 + l15;
+                const int rowb = m0 + wm * WM + mi * 16 + slot * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rowb + r < g.M && col < g.N) slab[(size_t)(rowb + r) * g.ld_slab + col] = acc[mi][ni][r];
+            }
+        return;
+    }
+
+    // ---------------- epilogue: bias + activation + draw; planes leave through an LDS patch ----
+    constexpr int LPR = WN / 8;          // lanes per output row, 8 bf16 = 16 B each
+    constexpr int RPI = 64 / LPR;
+    constexpr int NPASS = (WM + RPI - 1) / RPI;
+    constexpr int LPRT = WM / 8;         // transposed plane: lanes per row of outT
+    constexpr int RPIT = 64 / LPRT;
+    constexpr int NPASST = (WN + RPIT - 1) / RPIT;
+    float* patch = reinterpret_cast<float*>(smem) + wave * (WM * LDE);
+
+    float pv[TM][TN][4], sv[TM][TN][4], uv[TM][TN][4];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int col = n0 + wn * WN + ni * 16 + l15;
+        const float bias = (col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int rowb = m0 + wm * WM + mi * 16 + slot * 4;
+            uint32_t w[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
+            if (NOISE != NOISE_NONE) {
+                const uint64_t grow = g.rng.row0 + (uint64_t)rowb;
+                philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step, g.rng.seed_lo,
+                              g.rng.seed_hi, w);
+                if (NOISE == NOISE_GAUSSIAN)
+                    philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id | 0x80000000u, g.rng.step,
+                                  g.rng.seed_lo, g.rng.seed_hi, w2);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = acc[mi][ni][r] + bias;
+                float p;
+                if (g.act == ACT_SIGMOID) p = sigmoidf_fast(x);
+                else if (g.act == ACT_RELU) p = fmaxf(x, 0.f);
+                else p = x;
+                float sm = p;
+                const float ua = u32_to_unit(w[r]);
+                if (NOISE == NOISE_BERNOULLI) {
+                    sm = (ua < p) ? 1.0f : 0.0f;
+                } else if (NOISE == NOISE_GAUSSIAN) {
+                    const float ub = u32_to_unit(w2[r]);
+                    sm = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * ub);
+                }
+                pv[mi][ni][r] = p; sv[mi][ni][r] = sm; uv[mi][ni][r] = ua;
+            }
+        }
+    }
+
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool want_diff = (g.ref32 != nullptr) || (g.ref16 != nullptr);
+    const int prow = lane / LPR, pc8 = lane - prow * LPR;
+    const bool lane_on = lane < RPI * LPR;
+    const int gcol = n0 + wn * WN + 8 * pc8;
+
+    // registers -> patch; then (a) whole rows of the row-major planes, (b) whole rows of the
+    // transposed bf16 plane, both 16 B per lane
+    auto flush = [&](const float (&val)[TM][TN][4], uint16_t* __restrict__ o16, uint16_t* __restrict__ o16T,
+                     float* __restrict__ o32, bool diff) {
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) patch[(mi * 16 + slot * 4 + r) * LDE + ni * 16 + l15] = val[mi][ni][r];
+        __syncthreads();
+        if (o16 || o32 || diff) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int lrow = ps * RPI + prow;
+                const int grow = m0 + wm * WM + lrow;
+                if (lane_on && lrow < WM && grow < g.M && gcol < g.ldo_cols) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + lrow * LDE + 8 * pc8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + lrow * LDE + 8 * pc8 + 4);
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    const int nval = g.N - gcol;   // <= 0 in the zero padding of the row
+                    if (o16) {   // rows of the bf16 planes are padded to 8 elements: the 16-B store stays inside
+                        u32x4 pk;
+                        pk.x = pack_bf16x2(nval > 0 ? v[0] : 0.f, nval > 1 ? v[1] : 0.f);
+                        pk.y = pack_bf16x2(nval > 2 ? v[2] : 0.f, nval > 3 ? v[3] : 0.f);
+                        pk.z = pack_bf16x2(nval > 4 ? v[4] : 0.f, nval > 5 ? v[5] : 0.f);
+                        pk.w = pack_bf16x2(nval > 6 ? v[6] : 0.f, nval > 7 ? v[7] : 0.f);
+                        *reinterpret_cast<u32x4*>(o16 + (size_t)grow * g.ldo + gcol) = pk;
+                    }
+                    if (o32) {
+                        float* o = o32 + (size_t)grow * g.ldo32 + gcol;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e < nval) o[e] = v[e];
+                    }
+                    if (diff) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e < nval) {
+                                const float rf = g.ref32 ? g.ref32[(size_t)grow * g.ldref32 + gcol + e]
+                                                         : bf16_bits_to_f32(g.ref16[(size_t)grow * g.ldref16 + gcol + e]);
+                                csum[e] += rf - v[e];
+                            }
+                    }
+                }
+            }
+        }
+        if (o16T) {
+            const int trow = lane / LPRT, tc8 = lane - trow * LPRT;   // row of outT = output column
+#pragma unroll
+            for (int ps = 0; ps < NPASST; ++ps) {
+                const int lcol = ps * RPIT + trow;
+                const int gn = n0 + wn * WN + lcol;
+                const int gb = m0 + wm * WM + 8 * tc8;
+                if (lane < RPIT * LPRT && lcol < WN && gn < g.N && gb < g.ldoT) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (gb + e < g.M) ? patch[(8 * tc8 + e) * LDE + lcol] : 0.f;
+                    u32x4 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                    pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+                    *reinterpret_cast<u32x4*>(o16T + (size_t)gn * g.ldoT + gb) = pk;
+                }
+            }
+        }
+    };
+    const bool on_sample = (NOISE != NOISE_NONE);
+    if (!on_sample) flush(pv, g.out, g.outT, g.out_f32, want_diff);
+    else {
+        if (g.prob_f32) flush(pv, nullptr, nullptr, g.prob_f32, false);
+        flush(sv, g.out, g.outT, g.out_f32, want_diff);
+        if (g.out_u) flush(uv, nullptr, nullptr, g.out_u, false);
+    }
+
+    if (want_diff) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);   // [WAVES_M * RPI][BN]
+        if (lane_on) {
+            float* dst = red + (wm * RPI + prow) * BN + wn * WN + 8 * pc8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[e] = csum[e];
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < WAVES_M * RPI; ++i) t += red[i * BN + tid];
+            if (n0 + tid < g.N) g.colpart[(size_t)bm * g.ld_colpart + n0 + tid] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
+                              uint16_t* outT, int ldoT, int outT_rows, hipStream_t st) {
+    // cover the padded extents of whichever mirrors are requested
+    int r_ext = rows, c_ext = cols;
+    if (out) { if (out_rows > r_ext) r_ext = out_rows; if (ldo > c_ext) c_ext = ldo; }
+    if (outT) { if (ldoT > r_ext) r_ext = ldoT; if (outT_rows > c_ext) c_ext = outT_rows; }
+    dim3 grid((c_ext + 31) / 32, (r_ext + 31) / 32);
+    hipLaunchKernelGGL(k_f32_to_bf16, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
+                       outT_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_bf16(int epi, const GemmArgsB& g, hipStream_t st) {
+    const int nblk = g.grid_m * g.grid_n * g.nsplit;
+#define KURBM_B(E, NZ)                                                                              \
+    if (epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) {                                         \
+        hipLaunchKernelGGL((k_gemm_bf16<128, 128, 2, 2, E, NZ>), dim3(nblk), dim3(NTH), 0, st, g);  \
+        return hipGetLastError();                                                                   \
+    }
+    KURBM_B(EPI_HALFSTEP, NOISE_NONE)
+    KURBM_B(EPI_HALFSTEP, NOISE_BERNOULLI)
+    KURBM_B(EPI_HALFSTEP, NOISE_GAUSSIAN)
+    KURBM_B(EPI_SLAB, NOISE_NONE)
+#undef KURBM_B
+    return hipErrorInvalidValue;
+}
+
+}  // namespace kurbm

@@ -98,7 +98,45 @@ struct FinishArgs {
     int rows, n_vis, ldv, ncol_tiles, ld_rowpart;
 };
 
+// bf16 NT GEMM (kurbm_bf16.hip): A [M][lda], B [N][ldb] bf16, k contiguous and zero-padded to 128
+struct GemmArgsB {
+    const uint16_t* A0;
+    const uint16_t* B0;
+    const uint16_t* A1;   // segment 1 enters negated (statistics GEMM)
+    const uint16_t* B1;
+    int lda, ldb;         // elements, multiples of 8
+    int M, N, K;          // K per segment, multiple of 128
+    int nseg, nkt, kt_total, kt_per_split, nsplit;
+    int grid_m, grid_n;
+    // half-step epilogue
+    const float* bias;
+    int act, noise;
+    RngArgs rng;
+    uint16_t* out;        // bf16 [M][ldo]   value plane (sample, or prob when noise = NONE); nullable
+    int ldo;
+    int ldo_cols;         // columns the row planes cover: ldo when `out` is set (pads are zeroed), else N
+    uint16_t* outT;       // bf16 [N][ldoT]  the same plane transposed; nullable
+    int ldoT;
+    float* out_f32;       // fp32 copy of the value plane (persistent chain, tests); nullable
+    float* prob_f32;      // fp32 probabilities next to a sampled plane (tests); nullable
+    float* out_u;         // fp32 uniforms (tests); nullable
+    int ldo32;
+    const float* ref32;   // column partials of (ref - value): fp32 reference ...
+    int ldref32;
+    const uint16_t* ref16;  // ... or bf16 reference
+    int ldref16;
+    float* colpart;
+    int ld_colpart;
+    // slab epilogue
+    float* slab;
+    size_t slab_stride;
+    int ld_slab;
+};
+
 void tile_shape(int cfg, int* bm, int* bn);
+hipError_t launch_gemm_bf16(int epi, const GemmArgsB& g, hipStream_t st);
+hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
+                              uint16_t* outT, int ldoT, int outT_rows, hipStream_t st);
 hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g, hipStream_t st);
 hipError_t launch_philox_uniform(float* out, int rows, int cols, int ld, const RngArgs& rng, hipStream_t st);
 hipError_t launch_reduce_apply(const ReduceArgs& a, hipStream_t st);

@@ -32,6 +32,7 @@
 #include <stdint.h>
 
 #include "kurbm_kernels.h"
+#include "kurbm_device.h"
 
 namespace kurbm {
 
@@ -50,41 +51,9 @@ namespace kurbm {
 #define KURBM_ON(bit) true
 #endif
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int BK = 32;          // k-tile
 constexpr int NTHREADS = 256;   // 4 waves
 constexpr int LDX = BK + 4;     // x-major LDS row (floats): 144 B, 16-B aligned, conflict-free b128
-
-// ------------------------------------------------------------------------------------
-// Philox4x32-10 (Random123 constants) -- same contract as oracle/philox.py
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a mul_hi / mul_lo pair
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
-        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ float u32_to_unit(uint32_t x) {
-    return __uint_as_float((x & 0x7FFFFFu) | 0x3F800000u) - 1.0f;
-}
-
-__device__ __forceinline__ float sigmoidf_fast(float x) {
-    return __fdividef(1.0f, 1.0f + __expf(-x));
-}
-
-__device__ __forceinline__ float softplusf(float x) {
-    return fmaxf(x, 0.0f) + log1pf(__expf(-fabsf(x)));
-}
 
 __global__ void k_philox_uniform(float* __restrict__ out, int rows, int cols, int ld, RngArgs rng) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;

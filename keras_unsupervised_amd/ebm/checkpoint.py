@@ -26,7 +26,7 @@ def save_rbm(rbm, stem):
         raise ValueError("cannot checkpoint an RBM that has not been built")
     W, b_h, b_v = rbm.get_weights()
     cfg = {k: v for k, v in rbm.get_config().items() if k in
-           ("hps", "output_dim", "name", "mode", "seed", "update_mode", "cd_k", "persistent")}
+           ("hps", "output_dim", "name", "mode", "seed", "update_mode", "cd_k", "persistent", "compute_dtype")}
     meta = {"format": "kurbm-rbm", "version": FORMAT_VERSION, "config": cfg, "input_dim": int(W.shape[0]),
             "update_count": int(rbm._update_count), "call_count": int(rbm._call_count)}
     os.makedirs(os.path.dirname(os.path.abspath(stem)), exist_ok=True)

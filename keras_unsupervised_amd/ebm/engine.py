@@ -107,6 +107,10 @@ class DeviceRBM:
         self._ws = None
         self._ws_rows = 0
         self.delta = None  # packed [V*H | H | V] sums, allocated on first use
+        self._mirror = None        # bf16 images of W in both orientations (compute_dtype='bf16')
+        self._mirror_stale = True
+        self._ws_b = None
+        self._ws_b_rows = 0
 
     # -- plumbing -------------------------------------------------------------------
     def _stream(self):
@@ -127,6 +131,28 @@ class DeviceRBM:
             self.delta = torch.zeros(n, dtype=torch.float32, device=self.device)
         return self.delta
 
+    # -- bf16 mirrors (extension: bf16 operands, fp32 accumulate, fp32 master weights) -----
+    def mirror(self):
+        """The bf16 images of W, refreshed if the fp32 master was written behind the library's back."""
+        if self._mirror is None:
+            n = self.lib.kurbm_bf16_mirror_bytes(self.ctx.handle, self.n_vis, self.n_hid)
+            self._mirror = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self._mirror_stale = True
+        if self._mirror_stale:
+            check(self.lib.kurbm_bf16_mirror_refresh(self.ctx.handle, C.byref(self.params), self._mirror.data_ptr(),
+                                                     self._mirror.numel(), self._stream()))
+            self._mirror_stale = False
+        return self._mirror
+
+    def workspace_bf16(self, rows, k=1):
+        if self._ws_b is None or rows > self._ws_b_rows:
+            n = self.lib.kurbm_bf16_workspace_bytes(self.ctx.handle, rows, self.n_vis, self.n_hid, k)
+            if n == 0:
+                raise _lib.KurbmError("kurbm_bf16_workspace_bytes failed")
+            self._ws_b = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self._ws_b_rows = rows
+        return self._ws_b
+
     def get_weights(self):
         return self.W.to_numpy(), self.b_h.cpu().numpy(), self.b_v.cpu().numpy()
 
@@ -135,6 +161,7 @@ class DeviceRBM:
             W = np.asarray(W, dtype=np.float32)
             assert W.shape == (self.n_vis, self.n_hid)
             self.W.t[:, : self.n_hid].copy_(torch.from_numpy(np.ascontiguousarray(W)))
+            self._mirror_stale = True
         if b_h is not None:
             self.b_h.copy_(torch.from_numpy(np.ascontiguousarray(b_h, dtype=np.float32)))
         if b_v is not None:
@@ -166,22 +193,43 @@ class DeviceRBM:
         return out
 
     def cd_step(self, v, rows, row_start, lr, seed, step, k=1, mode=MODE_VISIBLE_BERNOULLI, chain=0,
-                which=WHICH_ALL, apply=True, emit_delta=False, v_chain=None, row0=0, v_chain_row=0):
+                which=WHICH_ALL, apply=True, emit_delta=False, v_chain=None, row0=0, v_chain_row=0, bf16=False):
         """One CD-k update on rows [row_start, row_start+rows) of DeviceMatrix v."""
         with torch.cuda.device(self.device):
-            ws = self.workspace(rows, k)
             opts = CdOpts(int(k), int(mode), float(lr), 1 if apply else 0,
                           self.delta_buffer().data_ptr() if emit_delta else None,
                           v_chain.ptr(v_chain_row) if v_chain is not None else None,
                           int(seed), int(row0), int(step) & 0xFFFFFFFF, int(chain))
+            if bf16:
+                mir, ws = self.mirror(), self.workspace_bf16(rows, k)
+                check(self.lib.kurbm_cd_step_bf16(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                                  v.ptr(row_start), rows, v.ld, C.byref(opts), int(which),
+                                                  ws.data_ptr(), ws.numel(), self._stream()))
+                return
+            ws = self.workspace(rows, k)
             check(self.lib.kurbm_cd_step(self.ctx.handle, C.byref(self.params), v.ptr(row_start), rows, v.ld,
                                          C.byref(opts), int(which), ws.data_ptr(), ws.numel(), self._stream()))
+
+    def half_step_bf16(self, direction, x, rows, act, noise, seed, stream_id, step, row0=0):
+        """Test hook: one half step with bf16 products; returns fp32 planes (sample, prob, u)."""
+        n_out = self.n_hid if direction == "vh" else self.n_vis
+        with torch.cuda.device(self.device):
+            mir, ws = self.mirror(), self.workspace_bf16(rows)
+            out = {k: DeviceMatrix.zeros(rows, n_out, self.device) for k in ("sample", "prob", "u")}
+            rng = Rng(int(seed), int(row0), int(stream_id) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF)
+            check(self.lib.kurbm_half_step_bf16(
+                self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), 0 if direction == "vh" else 1,
+                x.ptr(), rows, x.ld, act, noise, C.byref(rng), out["sample"].ptr() if noise else None,
+                out["prob"].ptr(), out["u"].ptr() if noise else None, round_up(n_out, 4), ws.data_ptr(), ws.numel(),
+                self._stream()))
+        return out
 
     def apply_delta(self, lr, which=WHICH_ALL, delta=None):
         delta = self.delta_buffer() if delta is None else delta
         with torch.cuda.device(self.device):
             check(self.lib.kurbm_apply_delta(self.ctx.handle, C.byref(self.params), delta.data_ptr(), float(lr),
                                              int(which), self._stream()))
+        self._mirror_stale = True
 
     def free_energy(self, v, rows, row_start=0):
         with torch.cuda.device(self.device):

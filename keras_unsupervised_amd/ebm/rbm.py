@@ -57,6 +57,9 @@ class RBM(object):
             raise ValueError("update_mode must be one of %s" % (_UPDATE_MODES,))
         self.cd_k = int(opt("cd_k", 1))
         self.persistent = bool(opt("persistent", False))
+        self.compute_dtype = str(opt("compute_dtype", "fp32"))   # 'bf16': bf16 operands, fp32 accumulate (extension)
+        if self.compute_dtype not in ("fp32", "bf16"):
+            raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
         self.list_returns = bool(kwargs.pop("ku_compat_list_returns", True))
         self._device_arg = kwargs.pop("device", None)
         self._init_weights = kwargs.pop("weights", None)
@@ -259,12 +262,13 @@ class RBM(object):
         d = self._dev
         if self.update_mode == "fused":
             d.cd_step(Vd, rows, lo, lr, self.seed, step, k=self.cd_k, mode=self.mode, chain=CHAIN_W,
-                      v_chain=self._v_chain if self.persistent else None)
+                      v_chain=self._v_chain if self.persistent else None, bf16=(self.compute_dtype == "bf16"))
         else:
             # the reference's three K.function calls: each its own chain, each seeing the variables
             # the previous call already updated (rbm.py:214-216)
             for chain, which in ((CHAIN_W, _lib.WHICH_W), (CHAIN_BH, _lib.WHICH_BH), (CHAIN_BV, _lib.WHICH_BV)):
-                d.cd_step(Vd, rows, lo, lr, self.seed, step, k=1, mode=self.mode, chain=chain, which=which)
+                d.cd_step(Vd, rows, lo, lr, self.seed, step, k=1, mode=self.mode, chain=chain, which=which,
+                          bf16=(self.compute_dtype == "bf16"))
 
     def _update_data_parallel(self, Vd, lo, rows, lr, step, rank, world):
         """Each rank: chain on its rows -> packed sums -> one all-reduce -> identical apply."""
@@ -276,7 +280,8 @@ class RBM(object):
         if s_hi > s_lo:
             d.cd_step(Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,
                       chain=CHAIN_W, apply=False, emit_delta=True, row0=s_lo,
-                      v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo)
+                      v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo,
+                      bf16=(self.compute_dtype == "bf16"))
         else:
             delta.zero_()
         dp.allreduce_sum_(delta)
@@ -288,7 +293,7 @@ class RBM(object):
         extension knobs, so that RBM(**config) rebuilds the same layer."""
         config = {"hps": self.hps, "output_dim": self.output_dim, "name": self.name, "mode": self.mode,
                   "seed": self.seed, "update_mode": self.update_mode, "cd_k": self.cd_k,
-                  "persistent": self.persistent}
+                  "persistent": self.persistent, "compute_dtype": self.compute_dtype}
         return dict(list(self._kwargs.items()) + list(config.items()))
 
 

@@ -61,6 +61,33 @@ def init_params(n_vis, n_hid, seed=0, dtype=np.float32):
     return W, b_h, b_v
 
 
+def bf16_round(x):
+    """float32 -> nearest-even bf16 -> float32: what the bf16 kernels feed the matrix cores.
+
+    Extension of the build (BASELINE.json config 5), absent from the reference.  Products of two bf16
+    values are exact in float32 and the MFMA accumulates in float32, so a float32 matmul of rounded
+    operands is the CPU statement of the bf16 path."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) >> np.uint64(16)) << np.uint64(16)
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def cd_step_fused_bf16(W, b_h, b_v, v_batch, lr, seed, step, k=1, row0=0, mode=MODE_VISIBLE_BERNOULLI, v_chain=None):
+    """cd_step_fused with every matrix-product operand rounded to bf16 (weights, data, the h_neg
+    probabilities; 0/1 samples are exact); biases, activations, sums and the update stay float32 and
+    the update is applied to the float32 master weights."""
+    Wq = bf16_round(W)
+    rng = Rng(seed, step, row0)
+    ch = gibbs_chain(bf16_round(v_batch), Wq, b_h, b_v, rng, k=k, chain=CHAIN_W, mode=mode,
+                     v_chain=None if v_chain is None else bf16_round(v_chain))
+    vq, vn = bf16_round(v_batch), bf16_round(ch["v_neg"])
+    dW = vq.T @ ch["h_pos"] - vn.T @ bf16_round(ch["h_neg"])
+    db_h = ch["h_pos"].sum(axis=0) - ch["h_neg"].sum(axis=0)
+    db_v = v_batch.sum(axis=0) - ch["v_neg"].sum(axis=0)
+    lr = W.dtype.type(lr)
+    return W + lr * dW, b_h + lr * db_h, b_v + lr * db_v, ch, (dW, db_h, db_v)
+
+
 def sigmoid(x):
     one = x.dtype.type(1.0)
     return one / (one + np.exp(-x))
