@@ -196,6 +196,7 @@ static int half_step(kurbm_ctx* ctx, int layout, const kurbm_params* p, const fl
     g.ref = ref; g.ldref = ldref; g.colpart = colpart; g.ld_colpart = ld_colpart;
     g.act = act; g.noise = noise;
     if (rng) g.rng = *rng;
+    g.m_fastest = (g.grid_m < g.grid_n) ? 1 : 0;
     if (grid_m_out) *grid_m_out = g.grid_m;
     HIP_TRY(launch_gemm(layout, cfg, EPI_HALFSTEP, g, st));
     return KURBM_OK;
@@ -570,6 +571,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
     g.out_f32 = out_f32; g.prob_f32 = prob_f32; g.out_u = out_u; g.ldo32 = ldo32;
     g.ref32 = ref32; g.ldref32 = ldref32; g.ref16 = ref16; g.ldref16 = ldref16;
     g.colpart = colpart; g.ld_colpart = ld_colpart;
+    g.m_fastest = (g.grid_m < g.grid_n) ? 1 : 0;
     if (grid_m_out) *grid_m_out = g.grid_m;
     HIP_TRY(launch_gemm_bf16(EPI_HALFSTEP, g, st));
     return KURBM_OK;

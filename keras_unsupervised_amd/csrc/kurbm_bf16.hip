@@ -89,7 +89,10 @@ __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
     const int tiles_mn = g.grid_m * g.grid_n;
     const int z = bid / tiles_mn;
     const int tmn = bid - z * tiles_mn;
-    const int bm = tmn / g.grid_n, bn = tmn - bm * g.grid_n;
+    // walk the SHORTER grid dimension fastest: an XCD's contiguous run of tiles then spans the whole
+    // short dimension and a slice of the long one, which minimises the operand bytes its L2 must hold
+    const int bm = g.m_fastest ? tmn % g.grid_m : tmn / g.grid_n;
+    const int bn = g.m_fastest ? tmn / g.grid_m : tmn - bm * g.grid_n;
     const int m0 = bm * BM, n0 = bn * BN;
 
     const int t_begin = z * g.kt_per_split;
@@ -121,10 +124,12 @@ __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
         goffB[it] = (unsigned)(x * g.ldb + 8 * ch);
         soffB[it] = row * ROWB + 16 * ch;
     }
-    u32x4 ra[NA], rb[NB];
+    struct Regs { u32x4 a[NA], b[NB]; };
+    Regs r0, r1;   // two tiles in flight between global memory and LDS (fetched two tiles ahead)
     unsigned char* sA0 = smem;
     unsigned char* sB0 = smem + 2 * A_BYTES;
     constexpr bool SIGNED = (EPI == EPI_SLAB);
+    constexpr int NCH = NA + NB;
 
     auto tile_of = [&](int t, const uint16_t*& oa, const uint16_t*& ob, uint32_t& flip) {
         t = t < t_end ? t : t_end - 1;
@@ -134,59 +139,95 @@ __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
         ob = (seg ? g.B1 : g.B0) + k0;
         flip = seg ? 0x80008000u : 0u;   // sign bits of a bf16 pair: segment 1 enters negated
     };
-    auto fetch = [&](const uint16_t* oa, const uint16_t* ob) {
+    auto fetch = [&](Regs& R, int t) {
+        const uint16_t *oa, *ob;
+        uint32_t flip;
+        tile_of(t, oa, ob, flip);
 #pragma unroll
-        for (int it = 0; it < NA; ++it) ra[it] = *reinterpret_cast<const u32x4*>(oa + goffA[it]);
+        for (int it = 0; it < NA; ++it) R.a[it] = *reinterpret_cast<const u32x4*>(oa + goffA[it]);
 #pragma unroll
-        for (int it = 0; it < NB; ++it) rb[it] = *reinterpret_cast<const u32x4*>(ob + goffB[it]);
+        for (int it = 0; it < NB; ++it) R.b[it] = *reinterpret_cast<const u32x4*>(ob + goffB[it]);
     };
-    auto park = [&](int buf, uint32_t flip) {
+    // park chunks [c0, c1) of the tile held in R
+    auto park = [&](const Regs& R, int buf, uint32_t flip, int c0, int c1) {
         unsigned char* a = sA0 + buf * A_BYTES;
         unsigned char* b = sB0 + buf * B_BYTES;
 #pragma unroll
-        for (int it = 0; it < NA; ++it) {
-            u32x4 v = ra[it];
-            if (SIGNED) { v.x ^= flip; v.y ^= flip; v.z ^= flip; v.w ^= flip; }
-            *reinterpret_cast<u32x4*>(a + soffA[it]) = v;
+        for (int c = 0; c < NCH; ++c) {
+            if (c < c0 || c >= c1) continue;
+            if (c < NA) {
+                u32x4 v = R.a[c];
+                if (SIGNED) { v.x ^= flip; v.y ^= flip; v.z ^= flip; v.w ^= flip; }
+                *reinterpret_cast<u32x4*>(a + soffA[c]) = v;
+            } else {
+                *reinterpret_cast<u32x4*>(b + soffB[c - NA]) = R.b[c - NA];
+            }
         }
+    };
+    auto frags = [&](int buf, int ks, u32x4 (&fa)[TM], u32x4 (&fb)[TN]) {
+        const unsigned char* cA = sA0 + buf * A_BYTES + (wm * WM + l15) * ROWB + 16 * slot + 64 * ks;
+        const unsigned char* cB = sB0 + buf * B_BYTES + (wn * WN + l15) * ROWB + 16 * slot + 64 * ks;
 #pragma unroll
-        for (int it = 0; it < NB; ++it) *reinterpret_cast<u32x4*>(b + soffB[it]) = rb[it];
+        for (int mi = 0; mi < TM; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(cA + mi * 16 * ROWB);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(cB + ni * 16 * ROWB);
+    };
+    auto mfmas = [&](const u32x4 (&fa)[TM], const u32x4 (&fb)[TN]) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]), acc[mi][ni], 0, 0, 0);
+    };
+    u32x4 fax[TM], fbx[TN], fay[TM], fby[TN];   // fragment double buffer: k-step s in x, s+1 in y, ...
+
+    // One 128-deep tile = 4 k-steps of 32, software pipelined (same idea as the fp32 kernel):
+    //   k-step 0  request tile i+2 from global memory (registers L); read k-step 1 fragments
+    //   k-step 1  park the first half of tile i+1 (registers P, fetched a whole tile ago); read k-step 2
+    //   k-step 2  park the second half; read k-step 3; then the tile's ONLY barrier
+    //   k-step 3  read the NEXT tile's k-step 0 fragments from the other buffer
+    // Every k-step's fragment reads are issued one step ahead of the MFMAs that use them.
+    auto one_tile = [&](int i, const int cur, Regs& L, const Regs& P) {
+        const uint16_t *oa, *ob;
+        uint32_t flip_p;
+        tile_of(t_begin + i + 1, oa, ob, flip_p);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(L, t_begin + i + 2);
+        frags(cur, 1, fay, fby);
+        mfmas(fax, fbx);
+        __builtin_amdgcn_sched_barrier(0);
+        park(P, cur ^ 1, flip_p, 0, NCH / 2);
+        frags(cur, 2, fax, fbx);
+        mfmas(fay, fby);
+        __builtin_amdgcn_sched_barrier(0);
+        park(P, cur ^ 1, flip_p, NCH / 2, NCH);
+        frags(cur, 3, fay, fby);
+        mfmas(fax, fbx);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        frags(cur ^ 1, 0, fax, fbx);
+        mfmas(fay, fby);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     if (nt > 0) {
         const uint16_t *oa, *ob;
         uint32_t flip;
         tile_of(t_begin, oa, ob, flip);
-        fetch(oa, ob);
-        park(0, flip);
+        fetch(r0, t_begin);
+        park(r0, 0, flip, 0, NCH);
+        fetch(r1, t_begin + 1);
         __syncthreads();
-        // k loop: fetch tile i+1 into registers before the MFMAs of tile i, park it after them.
-        // Branch-free: past the end the last tile is fetched / parked again (in bounds, never read).
-        for (int i = 0; i < nt; ++i) {
-            const int cur = i & 1;
-            tile_of(t_begin + i + 1, oa, ob, flip);
-            fetch(oa, ob);
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* cA = sA0 + cur * A_BYTES + (wm * WM + l15) * ROWB + 16 * slot;
-            const unsigned char* cB = sB0 + cur * B_BYTES + (wn * WN + l15) * ROWB + 16 * slot;
-#pragma unroll
-            for (int ks = 0; ks < BKB / 32; ++ks) {
-                u32x4 fa[TM], fb[TN];
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi) fa[mi] = *reinterpret_cast<const u32x4*>(cA + mi * 16 * ROWB + 64 * ks);
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(cB + ni * 16 * ROWB + 64 * ks);
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]), acc[mi][ni], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            park(cur ^ 1, flip);
-            __syncthreads();
+        frags(0, 0, fax, fbx);
+        // unrolled by two: register sets and LDS buffers alternate statically.  Branch-free: past the
+        // end of the slice the last tile is fetched / parked again (in bounds, never read).
+        int i = 0;
+        for (; i + 1 < nt; i += 2) {
+            one_tile(i, 0, r0, r1);
+            one_tile(i + 1, 1, r1, r0);
         }
+        if (i < nt) one_tile(i, 0, r0, r1);
     }
     __syncthreads();
 

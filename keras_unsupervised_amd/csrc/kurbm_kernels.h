@@ -34,6 +34,7 @@ struct GemmArgs {
     int kt_per_split;   // full k-tiles per split-K slice
     int nsplit;         // slices; the last one also takes the tail tiles
     int grid_m, grid_n;
+    int m_fastest;      // tile order inside a k-slice: 1 = m index fastest (see k_gemm)
     // half-step epilogue
     const float* bias;
     float* out_sample;
@@ -108,6 +109,7 @@ struct GemmArgsB {
     int M, N, K;          // K per segment, multiple of 128
     int nseg, nkt, kt_total, kt_per_split, nsplit;
     int grid_m, grid_n;
+    int m_fastest;
     // half-step epilogue
     const float* bias;
     int act, noise;

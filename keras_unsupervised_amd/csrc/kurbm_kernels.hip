@@ -217,7 +217,10 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
     const int tiles_mn = g.grid_m * g.grid_n;
     const int z = bid / tiles_mn;
     const int tmn = bid - z * tiles_mn;
-    const int bm = tmn / g.grid_n, bn = tmn - bm * g.grid_n;
+    // walk the SHORTER grid dimension fastest: an XCD's contiguous run of tiles then spans the whole
+    // short dimension and a slice of the long one, which minimises the operand bytes its L2 must hold
+    const int bm = g.m_fastest ? tmn % g.grid_m : tmn / g.grid_n;
+    const int bn = g.m_fastest ? tmn / g.grid_m : tmn - bm * g.grid_n;
     const int m0 = bm * BM, n0 = bn * BN;
 
     // k space: `nseg` segments of extent K; each has nfull = K / 32 full tiles (+ one partial
