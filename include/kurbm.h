@@ -155,6 +155,17 @@ int kurbm_cd_step(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, i
                   const kurbm_cd_opts* opts, int which, void* workspace, size_t workspace_bytes,
                   kurbm_stream_t stream);
 
+/*
+ * One pass of the training loop over a resident data matrix: for each contiguous batch, in order,
+ * remainder last (rbm.py:110-111, :163, :211, :218), one kurbm_cd_step with opts->step advancing by
+ * one per batch.  Replaces the Python-level batch loop of RBM.fit for update_mode "fused" when no
+ * per-step score is requested; identical launches, no host round trip per step.  A persistent
+ * chain (opts->v_chain) must hold batch_size rows.  Returns the number of steps taken (>= 0) or an
+ * error code (< 0).
+ */
+int kurbm_cd_epoch(kurbm_ctx* ctx, const kurbm_params* p, const float* V, int n_rows, int ldv, int batch_size,
+                   const kurbm_cd_opts* opts, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
 /* params += lr * delta for a packed delta (after the data-parallel all-reduce). */
 int kurbm_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, const float* delta, float lr,
                       int which, kurbm_stream_t stream);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "kurbm_half_step_hv_dbg": (_i, [_vp, _PP, _vp, _i, _i, _i, _i, _RP, _vp, _vp, _vp, _i, _vp]),
     "kurbm_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "kurbm_cd_step": (_i, [_vp, _PP, _vp, _i, _i, _OP, _i, _vp, _sz, _vp]),
+    "kurbm_cd_epoch": (_i, [_vp, _PP, _vp, _i, _i, _i, _OP, _vp, _sz, _vp]),
     "kurbm_apply_delta": (_i, [_vp, _PP, _vp, C.c_float, _i, _vp]),
     "kurbm_free_energy": (_i, [_vp, _PP, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "kurbm_outer_delta": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

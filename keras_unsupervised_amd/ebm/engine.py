@@ -210,6 +210,19 @@ class DeviceRBM:
             check(self.lib.kurbm_cd_step(self.ctx.handle, C.byref(self.params), v.ptr(row_start), rows, v.ld,
                                          C.byref(opts), int(which), ws.data_ptr(), ws.numel(), self._stream()))
 
+    def cd_epoch(self, v, n_rows, batch_size, lr, seed, step0, k=1, mode=MODE_VISIBLE_BERNOULLI, v_chain=None):
+        """All batches of one epoch in ONE library call (fp32, fused updates, no score); returns #steps."""
+        with torch.cuda.device(self.device):
+            ws = self.workspace(min(batch_size, max(n_rows, 1)), k)
+            opts = CdOpts(int(k), int(mode), float(lr), 1, None, v_chain.ptr() if v_chain is not None else None,
+                          int(seed), 0, int(step0) & 0xFFFFFFFF, 0)
+            n = self.lib.kurbm_cd_epoch(self.ctx.handle, C.byref(self.params), v.ptr(), int(n_rows), v.ld,
+                                        int(batch_size), C.byref(opts), ws.data_ptr(), ws.numel(), self._stream())
+            if n < 0:
+                check(n)
+        self._mirror_stale = True
+        return n
+
     def half_step_bf16(self, direction, x, rows, act, noise, seed, stream_id, step, row0=0):
         """Test hook: one half step with bf16 products; returns fp32 planes (sample, prob, u)."""
         n_out = self.n_hid if direction == "vh" else self.n_vis
