@@ -496,3 +496,30 @@ def test_epoch_call_equals_step_loop(gpu_device):
         b.cd_step(vd, hi - lo, lo, 0.01, 9, 5 + i, k=2)
     for x, y in zip(a.get_weights(), b.get_weights()):
         assert np.array_equal(x, y)
+
+
+def test_random_shape_sweep(gpu_device):
+    """Seeded sweep over awkward shapes (not multiples of 4 / 16 / 32 / the tiles; tiny and ragged
+    batches; k tails of every residue class): half steps, CD-k delta and free energy vs the oracle."""
+    rs = np.random.RandomState(2026)
+    for case in range(14):
+        B = int(rs.choice([1, 2, 5, 31, 33, 63, 65, 100, 129, 200, 257]))
+        nv = int(rs.randint(3, 400))
+        nh = int(rs.randint(3, 400))
+        k = int(rs.choice([1, 1, 2]))
+        W, b_h, b_v = synthetic_params(nv, nh, seed=900 + case)
+        v = synthetic_binary(B, nv, seed=950 + case, p=0.4)
+        e = _engine(W, b_h, b_v, gpu_device)
+        vd = _dm(v, gpu_device)
+        rng = O.Rng(case, 7)
+        out = e.half_step("vh", vd, B, 0, 0, 1, case, 0, 7, want_prob=True, want_u=True)
+        check_half_step(out, *O.sample_hidden(v, W, b_h, rng, 0))
+        h = out["sample"].to_numpy()
+        out2 = e.half_step("hv", out["sample"], B, 0, 0, 1, case, 1, 7, want_prob=True, want_u=True)
+        check_half_step(out2, *O.sample_visible(h, W, b_v, rng, 1))
+        F = e.free_energy(vd, B).cpu().numpy()
+        assert rel_err(F, O.free_energy(v, W, b_h, b_v)) <= TOL, (case, B, nv, nh)
+        d = _gpu_cd_delta(e, vd, B, 0.01, case, 3, k=k)
+        _, _, _, _, (dW_ref, dbh_ref, dbv_ref) = O.cd_step_fused(W, b_h, b_v, v, 0.01, case, 3, k=k)
+        dW, dbh, dbv = _split(d, nv, nh)
+        assert rel_err(dW, dW_ref) <= TOL and rel_err(dbh, dbh_ref) <= TOL and np.array_equal(dbv, dbv_ref), (case, B, nv, nh, k)
