@@ -27,8 +27,6 @@ namespace kurbm {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BKB = 128;                 // k-tile in bf16 elements (256 B per row)
-constexpr int ROWB = 2 * BKB + 16;       // LDS row in bytes: +16 B pad -> conflict-free ds_read_b128
 constexpr int NTH = 256;
 
 // ------------------------------------------------------------------------------------
@@ -61,14 +59,20 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
 // ------------------------------------------------------------------------------------
 // the bf16 NT GEMM
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NOISE>
+// BKB = k-tile in bf16 elements (2 * BKB bytes per LDS row, + 16 B pad -> conflict-free ds_read_b128).
+// <128,128,BKB 128>: one workgroup per CU (139 KB LDS);  <128,64,BKB 64>: 55 KB, two per CU, whose
+// MFMAs and staging instructions overlap across the two co-resident waves of a SIMD.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int EPI, int NOISE>
 __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    constexpr int ROWB = 2 * BKB + 16;
+    constexpr int CPR = BKB / 8;          // 16-B chunks per row
+    constexpr int KS = BKB / 32;          // MFMA k-steps per tile
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    constexpr int NA = BM * 16 / NTH, NB = BN * 16 / NTH;   // 16-B chunks per lane per tile
-    static_assert((BM * 16) % NTH == 0 && (BN * 16) % NTH == 0, "whole chunks per lane");
+    constexpr int NA = BM * CPR / NTH, NB = BN * CPR / NTH;   // 16-B chunks per lane per tile
+    static_assert((BM * CPR) % NTH == 0 && (BN * CPR) % NTH == 0, "whole chunks per lane");
     constexpr int LDE = WN + 4;
     constexpr int EPI_BYTES = 4 * WM * LDE * 4;
     constexpr int SMEM_BYTES = (2 * (A_BYTES + B_BYTES) > EPI_BYTES) ? 2 * (A_BYTES + B_BYTES) : EPI_BYTES;
@@ -106,20 +110,20 @@ __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // per-lane staging map: chunk q -> (row q / 16, 16-B chunk q % 16); rows outside the matrix are
+    // per-lane staging map: chunk q -> (row q / CPR, 16-B chunk q % CPR); rows outside the matrix are
     // pointed at row 0 (they only feed outputs that are never stored)
     unsigned goffA[NA], goffB[NB];
     int soffA[NA], soffB[NB];
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
-        const int q = it * NTH + tid, row = q >> 4, ch = q & 15;
+        const int q = it * NTH + tid, row = q / CPR, ch = q % CPR;
         const int x = (m0 + row < g.M) ? m0 + row : 0;
         goffA[it] = (unsigned)(x * g.lda + 8 * ch);
         soffA[it] = row * ROWB + 16 * ch;
     }
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
-        const int q = it * NTH + tid, row = q >> 4, ch = q & 15;
+        const int q = it * NTH + tid, row = q / CPR, ch = q % CPR;
         const int x = (n0 + row < g.N) ? n0 + row : 0;
         goffB[it] = (unsigned)(x * g.ldb + 8 * ch);
         soffB[it] = row * ROWB + 16 * ch;
@@ -182,32 +186,36 @@ __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
     };
     u32x4 fax[TM], fbx[TN], fay[TM], fby[TN];   // fragment double buffer: k-step s in x, s+1 in y, ...
 
-    // One 128-deep tile = 4 k-steps of 32, software pipelined (same idea as the fp32 kernel):
-    //   k-step 0  request tile i+2 from global memory (registers L); read k-step 1 fragments
-    //   k-step 1  park the first half of tile i+1 (registers P, fetched a whole tile ago); read k-step 2
-    //   k-step 2  park the second half; read k-step 3; then the tile's ONLY barrier
-    //   k-step 3  read the NEXT tile's k-step 0 fragments from the other buffer
+    // One tile = KS k-steps of 32, software pipelined (same idea as the fp32 kernel):
+    //   first k-step      request tile i+2 from global memory (registers L)
+    //   middle k-steps    park tile i+1 (registers P, fetched a whole tile ago) in the other LDS buffer
+    //   before the last   the tile's ONLY barrier (all fragments of the current buffer have been read)
+    //   last k-step       read the NEXT tile's first fragments from the other buffer
     // Every k-step's fragment reads are issued one step ahead of the MFMAs that use them.
     auto one_tile = [&](int i, const int cur, Regs& L, const Regs& P) {
         const uint16_t *oa, *ob;
         uint32_t flip_p;
         tile_of(t_begin + i + 1, oa, ob, flip_p);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(L, t_begin + i + 2);
-        frags(cur, 1, fay, fby);
-        mfmas(fax, fbx);
-        __builtin_amdgcn_sched_barrier(0);
-        park(P, cur ^ 1, flip_p, 0, NCH / 2);
-        frags(cur, 2, fax, fbx);
-        mfmas(fay, fby);
-        __builtin_amdgcn_sched_barrier(0);
-        park(P, cur ^ 1, flip_p, NCH / 2, NCH);
-        frags(cur, 3, fay, fby);
-        mfmas(fax, fbx);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        frags(cur ^ 1, 0, fax, fbx);
-        mfmas(fay, fby);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) fetch(L, t_begin + i + 2);
+            if (KS == 4) {
+                if (ks == 1) park(P, cur ^ 1, flip_p, 0, NCH / 2);
+                if (ks == 2) park(P, cur ^ 1, flip_p, NCH / 2, NCH);
+            } else if (ks == 0) {
+                park(P, cur ^ 1, flip_p, 0, NCH);
+            }
+            const bool last = (ks == KS - 1);
+            if (ks & 1) {   // fragments alternate x, y, x, y
+                if (!last) frags(cur, ks + 1, fax, fbx);
+                if (last) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); frags(cur ^ 1, 0, fax, fbx); }
+                mfmas(fay, fby);
+            } else {
+                frags(cur, ks + 1, fay, fby);
+                mfmas(fax, fbx);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -411,7 +419,8 @@ hipError_t launch_gemm_bf16(int epi, const GemmArgsB& g, hipStream_t st) {
     const int nblk = g.grid_m * g.grid_n * g.nsplit;
 #define KURBM_B(E, NZ)                                                                              \
     if (epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) {                                         \
-        hipLaunchKernelGGL((k_gemm_bf16<128, 128, 2, 2, E, NZ>), dim3(nblk), dim3(NTH), 0, st, g);  \
+        if (g.cfg == 1) hipLaunchKernelGGL((k_gemm_bf16<128, 64, 2, 2, 64, E, NZ>), dim3(nblk), dim3(NTH), 0, st, g);   \
+        else hipLaunchKernelGGL((k_gemm_bf16<128, 128, 2, 2, 128, E, NZ>), dim3(nblk), dim3(NTH), 0, st, g);            \
         return hipGetLastError();                                                                   \
     }
     KURBM_B(EPI_HALFSTEP, NOISE_NONE)
