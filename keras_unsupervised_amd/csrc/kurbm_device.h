@@ -30,7 +30,9 @@ __device__ __forceinline__ float u32_to_unit(uint32_t x) {
 }
 
 __device__ __forceinline__ float sigmoidf_fast(float x) {
-    return __fdividef(1.0f, 1.0f + __expf(-x));
+    // v_exp_f32 + v_rcp_f32 (1 ulp each): __fdividef expands to the full IEEE division sequence on
+    // gfx950 (div_scale / rcp / 4 fma / div_fmas / div_fixup), ten instructions per element
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
 __device__ __forceinline__ float softplusf(float x) {

@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kurbm_kernels.h"
 #include "kurbm_device.h"
 
@@ -433,41 +435,48 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
         const bool want_diff = (g.ref != nullptr);
 
         float pv[TM][TN][4], sv[TM][TN][4], uv[TM][TN][4];
+        // the activation is a launch-wide constant: branch on it ONCE, around the whole element nest
+        auto elementwise = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int col = n0 + wn * WN + ni * 16 + l15;
-            const float bias = (col < g.N) ? g.bias[col] : 0.f;
+            for (int ni = 0; ni < TN; ++ni) {
+                const int col = n0 + wn * WN + ni * 16 + l15;
+                const float bias = (col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const int rowb = m0 + wm * WM + mi * 16 + slot * 4;
-                uint32_t w[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
-                if (NOISE != NOISE_NONE) {
-                    const uint64_t grow = g.rng.row0 + (uint64_t)rowb;
-                    philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step,
-                                  g.rng.seed_lo, g.rng.seed_hi, w);
-                    if (NOISE == NOISE_GAUSSIAN)
-                        philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id | 0x80000000u,
-                                      g.rng.step, g.rng.seed_lo, g.rng.seed_hi, w2);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float x = acc[mi][ni][r] + bias;
-                    float p;
-                    if (g.act == ACT_SIGMOID) p = sigmoidf_fast(x);
-                    else if (g.act == ACT_RELU) p = fmaxf(x, 0.f);
-                    else p = x;
-                    float sm = p;
-                    const float ua = u32_to_unit(w[r]);
-                    if (NOISE == NOISE_BERNOULLI) {
-                        sm = (ua < p) ? 1.0f : 0.0f;
-                    } else if (NOISE == NOISE_GAUSSIAN) {
-                        const float ub = u32_to_unit(w2[r]);
-                        sm = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * ub);
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int rowb = m0 + wm * WM + mi * 16 + slot * 4;
+                    uint32_t w[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
+                    if (NOISE != NOISE_NONE) {
+                        const uint64_t grow = g.rng.row0 + (uint64_t)rowb;
+                        philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step,
+                                      g.rng.seed_lo, g.rng.seed_hi, w);
+                        if (NOISE == NOISE_GAUSSIAN)
+                            philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id | 0x80000000u,
+                                          g.rng.step, g.rng.seed_lo, g.rng.seed_hi, w2);
                     }
-                    pv[mi][ni][r] = p; sv[mi][ni][r] = sm; uv[mi][ni][r] = ua;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = acc[mi][ni][r] + bias;
+                        float p;
+                        if (ACT == ACT_SIGMOID) p = sigmoidf_fast(x);
+                        else if (ACT == ACT_RELU) p = fmaxf(x, 0.f);
+                        else p = x;
+                        float sm = p;
+                        const float ua = u32_to_unit(w[r]);
+                        if (NOISE == NOISE_BERNOULLI) {
+                            sm = (ua < p) ? 1.0f : 0.0f;
+                        } else if (NOISE == NOISE_GAUSSIAN) {
+                            const float ub = u32_to_unit(w2[r]);
+                            sm = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * ub);
+                        }
+                        pv[mi][ni][r] = p; sv[mi][ni][r] = sm; uv[mi][ni][r] = ua;
+                    }
                 }
             }
-        }
+        };
+        if (g.act == ACT_SIGMOID) elementwise(std::integral_constant<int, ACT_SIGMOID>{});
+        else if (g.act == ACT_RELU) elementwise(std::integral_constant<int, ACT_RELU>{});
+        else elementwise(std::integral_constant<int, ACT_LINEAR>{});
 
         float csum[4] = {0.f, 0.f, 0.f, 0.f};
         const int prow = lane / LPR, pc4 = lane - prow * LPR;   // this lane's place in a pass
