@@ -215,6 +215,7 @@ static int outer_slabs(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, c
     g.nkt = pl.nkt; g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
     g.grid_m = pl.gm; g.grid_n = pl.gn;
     g.slab = slab; g.slab_stride = slab_stride; g.ld_slab = pl.ld_slab;
+    g.tile_major = env_int("KURBM_TILE_MAJOR", 1);
     HIP_TRY(launch_gemm(LAYOUT_OUTER, pl.cfg, EPI_SLAB, g, st));
     return KURBM_OK;
 }
@@ -371,6 +372,11 @@ int kurbm_cd_step(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, i
     a.slab = w.slab; a.slab_stride = w.slab_stride; a.nslab = pl.nsplit; a.ld_slab = pl.ld_slab;
     a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw;
     a.nblk_w = need_w ? (int)(((long long)p->n_vis * (pl.ld_slab / 4) + 255) / 256) : 0;
+    if (need_w && env_int("KURBM_TILE_MAJOR", 1)) {
+        tile_shape(pl.cfg, &a.tile_bm, &a.tile_bn);
+        a.grid_m = pl.gm; a.grid_n = pl.gn; a.parts = 4; a.m_fastest = 0;
+        a.nblk_w = pl.gm * pl.gn * a.parts;
+    }
     a.lr = o->lr;
     const bool ap = o->apply != 0;
     a.W = (ap && (which & 1)) ? p->W : nullptr;
@@ -463,6 +469,11 @@ int kurbm_outer_delta(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, co
     a.slab = w.slab; a.slab_stride = w.slab_stride; a.nslab = pl.nsplit; a.ld_slab = pl.ld_slab;
     a.n_vis = n_vis; a.n_hid = n_hid; a.ldw = 0;
     a.nblk_w = (int)(((long long)n_vis * (pl.ld_slab / 4) + 255) / 256);
+    if (env_int("KURBM_TILE_MAJOR", 1)) {
+        tile_shape(pl.cfg, &a.tile_bm, &a.tile_bn);
+        a.grid_m = pl.gm; a.grid_n = pl.gn; a.parts = 4; a.m_fastest = 0;
+        a.nblk_w = pl.gm * pl.gn * a.parts;
+    }
     a.delta_w = delta_w;
     a.n_hid = n_hid;
     // no bias work: n_hid/n_vis bias blocks see null partial pointers and do nothing

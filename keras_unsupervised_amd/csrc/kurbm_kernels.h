@@ -35,6 +35,7 @@ struct GemmArgs {
     int nsplit;         // slices; the last one also takes the tail tiles
     int grid_m, grid_n;
     int m_fastest;      // tile order inside a k-slice: 1 = m index fastest (see k_gemm)
+    int tile_major;     // 1: k-slices of a tile are adjacent in the remapped block order (one XCD)
     // half-step epilogue
     const float* bias;
     float* out_sample;
@@ -69,6 +70,8 @@ struct ReduceArgs {
     int nslab, ld_slab;
     int n_vis, n_hid, ldw;
     int nblk_w;
+    // tile-ordered visit (tile_bm > 0): nblk_w = grid_m * grid_n * parts blocks, same XCD order as the GEMM
+    int tile_bm, tile_bn, grid_m, grid_n, parts, m_fastest;
     float lr;
     float* W;           // nullable: W += lr * dW
     float* delta_w;     // nullable: dense [n_vis][n_hid]

@@ -217,8 +217,11 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
         bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     }
     const int tiles_mn = g.grid_m * g.grid_n;
-    const int z = bid / tiles_mn;
-    const int tmn = bid - z * tiles_mn;
+    // tile_major (statistics GEMM): all k-slices of an output tile are neighbours in the remapped
+    // order, i.e. run on ONE XCD, and the reduce kernel visits tiles in the same order -- the slabs of
+    // a tile are then written and read back through the same L2 instead of crossing the fabric
+    const int z = g.tile_major ? bid % g.nsplit : bid / tiles_mn;
+    const int tmn = g.tile_major ? bid / g.nsplit : bid - z * tiles_mn;
     // walk the SHORTER grid dimension fastest: an XCD's contiguous run of tiles then spans the whole
     // short dimension and a slice of the long one, which minimises the operand bytes its L2 must hold
     const int bm = g.m_fastest ? tmn % g.grid_m : tmn / g.grid_n;
@@ -591,6 +594,56 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
 __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.nblk_w) {
+        if (a.tile_bm > 0) {
+            // tile order: the same XCD remap as the GEMM, then (tile, part of the tile)
+            const int nwg = a.nblk_w;
+            int bid = blockIdx.x;
+            const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+            bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+            const int tile = bid / a.parts, part = bid - tile * a.parts;
+            const int bm = a.m_fastest ? tile % a.grid_m : tile / a.grid_n;
+            const int bn = a.m_fastest ? tile / a.grid_m : tile - bm * a.grid_n;
+            const int g4 = a.tile_bn / 4;
+            const int rows_pp = (a.tile_bm + a.parts - 1) / a.parts;
+            // one block = rows_pp x tile_bn floats; lanes walk the float4 groups of a row
+            for (int e = tid; e < rows_pp * g4; e += 256) {
+                const int r = part * rows_pp + e / g4;
+                const int ii = bm * a.tile_bm + r, jj = bn * a.tile_bn + 4 * (e % g4);
+                if (r >= a.tile_bm || ii >= a.n_vis || jj >= a.n_hid) continue;
+                const float* sp = a.slab + (size_t)ii * a.ld_slab + jj;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                int zz = 0;
+                for (; zz + 4 <= a.nslab; zz += 4) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 0) * a.slab_stride);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 1) * a.slab_stride);
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 2) * a.slab_stride);
+                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 3) * a.slab_stride);
+                    s += v0; s += v1; s += v2; s += v3;
+                }
+                for (; zz < a.nslab; ++zz) s += *reinterpret_cast<const f32x4*>(sp + (size_t)zz * a.slab_stride);
+                if (jj + 3 < a.n_hid) {
+                    if (a.W) {
+                        f32x4* w = reinterpret_cast<f32x4*>(a.W + (size_t)ii * a.ldw + jj);
+                        *w = *w + s * a.lr;
+                    }
+                    if (a.delta_w) {
+                        float* d = a.delta_w + (size_t)ii * a.n_hid + jj;
+                        if ((a.n_hid & 3) == 0) *reinterpret_cast<f32x4*>(d) = s;
+                        else { d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w; }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (jj + u < a.n_hid) {
+                            if (a.delta_w) a.delta_w[(size_t)ii * a.n_hid + jj + u] = s[u];
+                            if (a.W) a.W[(size_t)ii * a.ldw + jj + u] += a.lr * s[u];
+                        }
+                }
+            }
+            return;
+        }
+    }
+    if ((int)blockIdx.x < a.nblk_w) {   // row order (no tile geometry given)
         const int groups = a.ld_slab / 4;  // float4 groups per row
         const long long q = (long long)blockIdx.x * 256 + tid;
         if (q >= (long long)a.n_vis * groups) return;
