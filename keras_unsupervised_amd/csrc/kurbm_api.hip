@@ -21,6 +21,7 @@ struct kurbm_ctx {
     // tuning overrides (environment, read once at ctx creation): -1 = automatic
     int force_cfg[3];   // per layout: KURBM_CFG_VH / KURBM_CFG_HV / KURBM_CFG_OUTER
     int force_split;    // KURBM_SPLIT
+    int tile_major;     // KURBM_TILE_MAJOR (default 1): k-slices of a statistics tile share an XCD
 };
 
 static int env_int(const char* name, int dflt) {
@@ -205,7 +206,6 @@ static int half_step(kurbm_ctx* ctx, int layout, const kurbm_params* p, const fl
 static int outer_slabs(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, const float* v_neg, const float* h_neg,
                        int rows, int n_vis, int n_hid, int ldv, int ldh, float* slab, size_t slab_stride,
                        const OuterPlan& pl, hipStream_t st) {
-    (void)ctx;
     GemmArgs g;
     memset(&g, 0, sizeof g);
     g.A0 = v_pos; g.A1 = v_neg; g.lda = ldv;
@@ -215,7 +215,7 @@ static int outer_slabs(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, c
     g.nkt = pl.nkt; g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
     g.grid_m = pl.gm; g.grid_n = pl.gn;
     g.slab = slab; g.slab_stride = slab_stride; g.ld_slab = pl.ld_slab;
-    g.tile_major = env_int("KURBM_TILE_MAJOR", 1);
+    g.tile_major = ctx->tile_major;
     HIP_TRY(launch_gemm(LAYOUT_OUTER, pl.cfg, EPI_SLAB, g, st));
     return KURBM_OK;
 }
@@ -244,6 +244,7 @@ int kurbm_ctx_create(int device, kurbm_ctx** out) {
     c->force_cfg[LAYOUT_HV] = env_int("KURBM_CFG_HV", -1);
     c->force_cfg[LAYOUT_OUTER] = env_int("KURBM_CFG_OUTER", -1);
     c->force_split = env_int("KURBM_SPLIT", -1);
+    c->tile_major = env_int("KURBM_TILE_MAJOR", 1);
     *out = c;
     return KURBM_OK;
 }
@@ -372,7 +373,7 @@ int kurbm_cd_step(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, i
     a.slab = w.slab; a.slab_stride = w.slab_stride; a.nslab = pl.nsplit; a.ld_slab = pl.ld_slab;
     a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw;
     a.nblk_w = need_w ? (int)(((long long)p->n_vis * (pl.ld_slab / 4) + 255) / 256) : 0;
-    if (need_w && env_int("KURBM_TILE_MAJOR", 1)) {
+    if (need_w && ctx->tile_major) {
         tile_shape(pl.cfg, &a.tile_bm, &a.tile_bn);
         a.grid_m = pl.gm; a.grid_n = pl.gn; a.parts = 4; a.m_fastest = 0;
         a.nblk_w = pl.gm * pl.gn * a.parts;
@@ -469,7 +470,7 @@ int kurbm_outer_delta(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, co
     a.slab = w.slab; a.slab_stride = w.slab_stride; a.nslab = pl.nsplit; a.ld_slab = pl.ld_slab;
     a.n_vis = n_vis; a.n_hid = n_hid; a.ldw = 0;
     a.nblk_w = (int)(((long long)n_vis * (pl.ld_slab / 4) + 255) / 256);
-    if (env_int("KURBM_TILE_MAJOR", 1)) {
+    if (ctx->tile_major) {
         tile_shape(pl.cfg, &a.tile_bm, &a.tile_bn);
         a.grid_m = pl.gm; a.grid_n = pl.gn; a.parts = 4; a.m_fastest = 0;
         a.nblk_w = pl.gm * pl.gn * a.parts;
