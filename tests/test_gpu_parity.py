@@ -523,3 +523,35 @@ def test_random_shape_sweep(gpu_device):
         _, _, _, _, (dW_ref, dbh_ref, dbv_ref) = O.cd_step_fused(W, b_h, b_v, v, 0.01, case, 3, k=k)
         dW, dbh, dbv = _split(d, nv, nh)
         assert rel_err(dW, dW_ref) <= TOL and rel_err(dbh, dbh_ref) <= TOL and np.array_equal(dbv, dbv_ref), (case, B, nv, nh, k)
+
+
+def test_data_parallel_emulation_two_shards(gpu_device):
+    """The N > 1 update sequence with the real kernels, two 'ranks' emulated on one GPU: each runs the
+    chain on its shard (global-row Philox counters), the packed deltas are summed (the all-reduce) and
+    applied on both replicas.  Replicas stay bit-identical and track the single-rank run within the fp32
+    summation-order band -- draws are identical whatever the shard count."""
+    from keras_unsupervised_amd.ebm import dp
+    nv, nh, B = 120, 88, 150          # ragged: shards of 76 and 74 rows
+    W0 = synthetic_params(nv, nh, seed=1000)
+    V = synthetic_binary(2 * B, nv, seed=1001, p=0.3)
+    vd = _dm(V, gpu_device)
+    single = _engine(*W0, gpu_device)
+    ranks = [_engine(*W0, gpu_device) for _ in range(2)]
+    lr = 0.01
+    for step in range(2):
+        lo = step * B
+        single.cd_step(vd, B, lo, lr, 21, step, k=2)
+        deltas = []
+        for r, e in enumerate(ranks):
+            s_lo, s_hi = dp.shard_rows(B, 2, r)
+            assert s_lo % 4 == 0
+            e.cd_step(vd, s_hi - s_lo, lo + s_lo, lr, 21, step, k=2, apply=False, emit_delta=True, row0=s_lo)
+            deltas.append(e.delta_buffer().clone())
+        total = deltas[0] + deltas[1]                      # what all_reduce(SUM) leaves on every rank
+        for e in ranks:
+            e.apply_delta(lr, delta=total)
+    torch.cuda.synchronize()
+    a, b, ref = ranks[0].get_weights(), ranks[1].get_weights(), single.get_weights()
+    for x, y, z in zip(a, b, ref):
+        assert np.array_equal(x, y)
+        assert np.max(np.abs(x - z)) <= 1e-5
