@@ -589,8 +589,11 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
     g.B0 = vh ? m.Wtb : m.Wb; g.ldb = vh ? m.Kv : m.Kh;
     g.M = rows; g.N = vh ? p->n_hid : p->n_vis; g.K = vh ? m.Kv : m.Kh;
     g.nseg = 1; g.nkt = g.K / 128; g.kt_total = g.nkt; g.kt_per_split = g.nkt; g.nsplit = 1;
-    // 128x64 tiles (two workgroups per CU) unless 128x128 tiles already give every CU two
-    g.cfg = env_int("KURBM_BF16_CFG", (ceil_div(rows, 128) * ceil_div(g.N, 128) < 2 * ctx->ncu) ? 1 : 0);
+    // tile choice: 128x128 when that already gives every CU two workgroups; the wave-specialised
+    // 128x128 kernel (4 MFMA + 4 loader waves, one workgroup per CU) when there is about one tile per
+    // CU; 128x64 tiles (more, smaller workgroups) for small grids
+    const int tiles128 = ceil_div(rows, 128) * ceil_div(g.N, 128);
+    g.cfg = env_int("KURBM_BF16_CFG", tiles128 >= 2 * ctx->ncu ? 0 : (2 * tiles128 >= ctx->ncu ? 2 : 1));
     g.grid_m = ceil_div(rows, 128); g.grid_n = ceil_div(g.N, 128) * (g.cfg == 1 ? 2 : 1);   // covers the 128-padded row
     if (g.cfg == 1) { g.nkt = g.K / 64; g.kt_total = g.nkt; g.kt_per_split = g.nkt; }
     g.bias = vh ? p->b_h : p->b_v;

@@ -64,8 +64,11 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
 // BKB = k-tile in bf16 elements (2 * BKB bytes per LDS row, + 16 B pad -> conflict-free ds_read_b128).
 // <128,128,BKB 128>: one workgroup per CU (139 KB LDS);  <128,64,BKB 64>: 55 KB, two per CU, whose
 // MFMAs and staging instructions overlap across the two co-resident waves of a SIMD.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int EPI, int NOISE>
-__global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
+// WS ("wave specialised", 512 threads): waves 0-3 only read fragments and issue MFMAs, waves 4-7 only
+// move tiles global -> registers -> LDS.  A bf16 MFMA leaves ~8 issue cycles per 16, far too few for the
+// staging instructions of its own wave; with a loader wave beside every MFMA wave they issue in parallel.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int EPI, int NOISE, bool WS = false>
+__global__ __launch_bounds__(WS ? 2 * NTH : NTH) void k_gemm_bf16(GemmArgsB g) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     constexpr int ROWB = 2 * BKB + 16;
     constexpr int CPR = BKB / 8;          // 16-B chunks per row
@@ -82,7 +85,10 @@ __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = WS && wave_all >= 4;      // wave-uniform role
+    const int wave = loader ? wave_all - 4 : wave_all;
+    const int stid = tid & (NTH - 1);             // staging thread id
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l15 = lane & 15, slot = lane >> 4;
 
@@ -106,26 +112,20 @@ __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
     if (t_end > g.kt_total) t_end = g.kt_total;
     const int nt = t_end > t_begin ? t_end - t_begin : 0;
 
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     // per-lane staging map: chunk q -> (row q / CPR, 16-B chunk q % CPR); rows outside the matrix are
     // pointed at row 0 (they only feed outputs that are never stored)
     unsigned goffA[NA], goffB[NB];
     int soffA[NA], soffB[NB];
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
-        const int q = it * NTH + tid, row = q / CPR, ch = q % CPR;
+        const int q = it * NTH + stid, row = q / CPR, ch = q % CPR;
         const int x = (m0 + row < g.M) ? m0 + row : 0;
         goffA[it] = (unsigned)(x * g.lda + 8 * ch);
         soffA[it] = row * ROWB + 16 * ch;
     }
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
-        const int q = it * NTH + tid, row = q / CPR, ch = q % CPR;
+        const int q = it * NTH + stid, row = q / CPR, ch = q % CPR;
         const int x = (n0 + row < g.N) ? n0 + row : 0;
         goffB[it] = (unsigned)(x * g.ldb + 8 * ch);
         soffB[it] = row * ROWB + 16 * ch;
@@ -170,6 +170,51 @@ __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
             }
         }
     };
+    if (WS && loader) {
+        // ---- loader waves: their own loop and their own registers (the roles share no live values, so
+        // the register allocator sees max(), not sum(), of the two roles' needs)
+        if (nt > 0) {
+            const uint16_t *oa, *ob;
+            uint32_t flip;
+            tile_of(t_begin, oa, ob, flip);
+            fetch(r0, t_begin);
+            park(r0, 0, flip, 0, NCH);
+            fetch(r1, t_begin + 1);
+            __syncthreads();
+            int i = 0;
+            for (; i + 1 < nt; i += 2) {
+                tile_of(t_begin + i + 1, oa, ob, flip);
+                fetch(r0, t_begin + i + 2);
+                park(r1, 1, flip, 0, NCH);
+                __syncthreads();
+                tile_of(t_begin + i + 2, oa, ob, flip);
+                fetch(r1, t_begin + i + 3);
+                park(r0, 0, flip, 0, NCH);
+                __syncthreads();
+            }
+            if (i < nt) {
+                tile_of(t_begin + i + 1, oa, ob, flip);
+                fetch(r0, t_begin + i + 2);
+                park(r1, 1, flip, 0, NCH);
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        if (EPI == EPI_SLAB) return;
+        // keep the MFMA waves' epilogue barriers company (same counts as below)
+        const bool diff = (g.ref32 != nullptr) || (g.ref16 != nullptr);
+        const int nflush = (NOISE != NOISE_NONE) ? 1 + (g.prob_f32 ? 1 : 0) + (g.out_u ? 1 : 0) : 1;
+        for (int f = 0; f < nflush; ++f) { __syncthreads(); __syncthreads(); }
+        if (diff) { __syncthreads(); __syncthreads(); }
+        return;
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     auto frags = [&](int buf, int ks, u32x4 (&fa)[TM], u32x4 (&fb)[TN]) {
         const unsigned char* cA = sA0 + buf * A_BYTES + (wm * WM + l15) * ROWB + 16 * slot + 64 * ks;
         const unsigned char* cB = sB0 + buf * B_BYTES + (wn * WN + l15) * ROWB + 16 * slot + 64 * ks;
@@ -201,12 +246,14 @@ __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) fetch(L, t_begin + i + 2);
-            if (KS == 4) {
-                if (ks == 1) park(P, cur ^ 1, flip_p, 0, NCH / 2);
-                if (ks == 2) park(P, cur ^ 1, flip_p, NCH / 2, NCH);
-            } else if (ks == 0) {
-                park(P, cur ^ 1, flip_p, 0, NCH);
+            if (!WS) {
+                if (ks == 0) fetch(L, t_begin + i + 2);
+                if (KS == 4) {
+                    if (ks == 1) park(P, cur ^ 1, flip_p, 0, NCH / 2);
+                    if (ks == 2) park(P, cur ^ 1, flip_p, NCH / 2, NCH);
+                } else if (ks == 0) {
+                    park(P, cur ^ 1, flip_p, 0, NCH);
+                }
             }
             const bool last = (ks == KS - 1);
             if (ks & 1) {   // fragments alternate x, y, x, y
@@ -225,9 +272,11 @@ __global__ __launch_bounds__(NTH) void k_gemm_bf16(GemmArgsB g) {
         const uint16_t *oa, *ob;
         uint32_t flip;
         tile_of(t_begin, oa, ob, flip);
-        fetch(r0, t_begin);
-        park(r0, 0, flip, 0, NCH);
-        fetch(r1, t_begin + 1);
+        if (!WS) {
+            fetch(r0, t_begin);
+            park(r0, 0, flip, 0, NCH);
+            fetch(r1, t_begin + 1);
+        }
         __syncthreads();
         frags(0, 0, fax, fbx);
         // unrolled by two: register sets and LDS buffers alternate statically.  Branch-free: past the
@@ -429,6 +478,7 @@ hipError_t launch_gemm_bf16(int epi, const GemmArgsB& g, hipStream_t st) {
 #define KURBM_B(E, NZ)                                                                              \
     if (epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) {                                         \
         if (g.cfg == 1) hipLaunchKernelGGL((k_gemm_bf16<128, 64, 2, 2, 64, E, NZ>), dim3(nblk), dim3(NTH), 0, st, g);   \
+        else if (g.cfg == 2) hipLaunchKernelGGL((k_gemm_bf16<128, 128, 2, 2, 128, E, NZ, true>), dim3(nblk), dim3(2 * NTH), 0, st, g); \
         else hipLaunchKernelGGL((k_gemm_bf16<128, 128, 2, 2, 128, E, NZ>), dim3(nblk), dim3(NTH), 0, st, g);            \
         return hipGetLastError();                                                                   \
     }

@@ -113,7 +113,8 @@ struct GemmArgsB {
     int nseg, nkt, kt_total, kt_per_split, nsplit;
     int grid_m, grid_n;
     int m_fastest;
-    int cfg;              // 0: 128x128 tile, k-tile 128 (one workgroup per CU); 1: 128x64, k-tile 64 (two per CU)
+    int cfg;              // 0: 128x128 tile, k-tile 128 (one workgroup per CU); 1: 128x64, k-tile 64 (two per CU);
+                          // 2: 128x128 / 128 wave-specialised (512 threads: 4 MFMA waves + 4 loader waves)
     // half-step epilogue
     const float* bias;
     int act, noise;
