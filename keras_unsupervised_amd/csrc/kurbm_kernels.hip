@@ -682,19 +682,29 @@ __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
         }
         return;
     }
+    // bias partials [row tiles][columns] -> column sums: eight loads in flight per lane, partial sums
+    // combined in a fixed order (bit-reproducible)
     const int q = ((int)blockIdx.x - a.nblk_w) * 256 + tid;
+    auto colsum = [](const float* __restrict__ part, int ntiles, int ld, int c) {
+        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int r = 0;
+        for (; r + 8 <= ntiles; r += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] += part[(size_t)(r + u) * ld + c];
+        }
+        for (; r < ntiles; ++r) t[0] += part[(size_t)r * ld + c];
+        return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    };
     if (q < a.n_hid) {
         if (a.part_h) {
-            float t = 0.f;
-            for (int r = 0; r < a.nrow_tiles_h; ++r) t += a.part_h[(size_t)r * a.ld_part_h + q];
+            const float t = colsum(a.part_h, a.nrow_tiles_h, a.ld_part_h, q);
             if (a.delta_bh) a.delta_bh[q] = t;
             if (a.b_h) a.b_h[q] += a.lr * t;
         }
     } else if (q < a.n_hid + a.n_vis) {
         const int c = q - a.n_hid;
         if (a.part_v) {
-            float t = 0.f;
-            for (int r = 0; r < a.nrow_tiles_v; ++r) t += a.part_v[(size_t)r * a.ld_part_v + c];
+            const float t = colsum(a.part_v, a.nrow_tiles_v, a.ld_part_v, c);
             if (a.delta_bv) a.delta_bv[c] = t;
             if (a.b_v) a.b_v[c] += a.lr * t;
         }
