@@ -13,16 +13,20 @@
 // :52-53 / :121-123 (h->v), :124 (h_neg), :125-134 (updates), :73-75 (free energy).
 //
 // Design notes (DESIGN.md has the long form):
-//   * 256 threads = 4 waves per workgroup, one wave per SIMD; every wave owns a WM x WN
-//     output tile as TM x TN accumulators of 16x16 (4 VGPRs each).
+//   * 256 threads = 4 waves per workgroup; every wave owns a WM x WN output tile as TM x TN
+//     accumulators of 16x16 (4 VGPRs each).  The host side sizes tiles and split-K so that two
+//     workgroups share a CU whenever the problem allows it.
 //   * K is consumed in tiles of 32.  Operands whose k index is contiguous in memory are
 //     staged "x-major" ([x][36]); a lane fetches 4 consecutive k with one ds_read_b128 and
 //     feeds them to 4 successive MFMAs.  The MFMA sums over k, so any pairing of k between
 //     the four k-slots of a 16x16x4 is valid as long as A and B agree: both use
 //     k(r, slot, t) = 16 r + 4 slot + t.  Operands whose k index is the slow one are staged
 //     "k-major" ([k][BX+4]) and read with ds_read_b32 at that same k.
-//   * Global -> register -> LDS staging, two LDS buffers, one barrier per k-tile; the
-//     loads of tile t+2 are issued before the MFMAs of tile t.
+//   * Global -> register -> LDS staging, two LDS buffers, ONE barrier per k-tile.  A tile is 8 MFMA
+//     groups; tile t+1 is fetched in groups 0-3, parked in groups 4-6, and the next tile's first
+//     fragments are read in group 7, all pinned between the MFMAs with sched_barrier(0).
+//   * The epilogue runs in the accumulator layout, then every output plane is transposed through a
+//     per-wave LDS patch so that global memory sees whole rows (16 B per lane).
 //   * The Philox block of an output element is keyed by (col, row >> 2): its four words are
 //     the four rows a lane holds in one 16x16 accumulator, so one Philox call serves one
 //     accumulator and no lane computes a block it does not use.
