@@ -136,3 +136,26 @@ def test_dbn_control_flow():
     assert feat.shape == (20, 6) and set(np.unique(feat)) <= {0.0, 1.0}
     back = O.dbn_inv_transform(layers, feat)
     assert back.shape == (20, 16)
+
+
+def test_second_opinion_torch():
+    """The oracle's arithmetic against an independent implementation (torch CPU, float64): half steps,
+    free energy and the CD statistics -- a typo in the restatement would have to exist twice."""
+    import torch
+    nv, nh, B = 50, 34, 20
+    W, b_h, b_v = synthetic_params(nv, nh, 13)
+    v = synthetic_real(B, nv, 14)
+    tW, tbh, tbv, tv = (torch.from_numpy(x.astype(np.float64)) for x in (W, b_h, b_v, v))
+    assert np.allclose(O.hidden_prob(v, W, b_h), torch.sigmoid(tv @ tW + tbh).numpy(), atol=2e-6)
+    h = synthetic_binary(B, nh, 15, p=0.5)
+    th = torch.from_numpy(h.astype(np.float64))
+    assert np.allclose(O.visible_prob(h, W, b_v), torch.sigmoid(th @ tW.T + tbv).numpy(), atol=2e-6)
+    F = -(tv @ tbv + torch.nn.functional.softplus(tv @ tW + tbh).sum(-1))
+    assert np.allclose(O.free_energy(v, W, b_h, b_v), F.numpy(), rtol=1e-5)
+    _, _, _, ch, (dW, dbh, dbv) = O.cd_step_fused(W, b_h, b_v, v, 0.1, 1, 0)
+    tp = lambda k: torch.from_numpy(ch[k].astype(np.float64))
+    assert np.allclose(dW, (tv.T @ tp("h_pos") - tp("v_neg").T @ tp("h_neg")).numpy(), atol=1e-4)
+    assert np.allclose(dbv, (tv.sum(0) - tp("v_neg").sum(0)).numpy(), atol=1e-4)
+    # bf16 rounding helper against torch's own conversion
+    x = np.linspace(-3, 3, 1001, dtype=np.float32) * np.float32(1.2345)
+    assert np.array_equal(O.bf16_round(x), torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy())
