@@ -220,6 +220,42 @@ int kurbm_half_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
                          float* out_sample, float* out_prob, float* out_u, int ld_out,
                          void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
 
+/* ---- x3: fp32 values as exact bf16 triples on the bf16 matrix cores (extension) ---------------
+ *
+ * gfx950 multiplies bf16 operands 16x faster than fp32 ones (v_mfma_f32_16x16x32_bf16 vs
+ * v_mfma_f32_16x16x4_f32), and every fp32 value is EXACTLY the sum of three bf16 values
+ * (x = hi + mid + lo, round-to-nearest at each stage).  The x3 entry points keep fp32 storage and
+ * fp32 accumulation, but carry each real-valued GEMM operand as its three pieces and run one
+ * k-segment of the product per pair of pieces; 0/1 samples (h_pos, v_neg, the hidden and visible
+ * states of a Bernoulli chain) are a single exact piece.  Products of pieces are exact in fp32, so the
+ * result differs from an fp32 GEMM only in the order of the fp32 additions.  Same reference
+ * operations as the fp32 entry points (rbm.py:46-47, :121-134); MODE_VISIBLE_BERNOULLI only.
+ *
+ * v_pieces: 1 promises that every element of v_batch (and of opts->v_chain) is exactly a bf16
+ * value, which 0/1 data is (check with kurbm_bf16_exact); 3 splits the batch as well.  When both
+ * operands of a product are split, the three pairs of pieces below 2^-24 of the product are left out.
+ * The mirror holds the pieces of W in both orientations and follows the rules of the bf16 mirror.
+ */
+size_t kurbm_x3_mirror_bytes(kurbm_ctx* ctx, int n_vis, int n_hid);
+int kurbm_x3_mirror_refresh(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                            kurbm_stream_t stream);
+size_t kurbm_x3_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int k, int v_pieces);
+
+/* Same contract as kurbm_cd_step. */
+int kurbm_cd_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                     const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts,
+                     int which, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
+/* One half step on the x3 path (transform / test hook): dir 0 = v->h, 1 = h->v. */
+int kurbm_half_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, int dir,
+                       const float* in, int in_pieces, int rows, int ld_in, int act, int noise,
+                       const kurbm_rng* rng, float* out_sample, float* out_prob, float* out_u, int ld_out,
+                       void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
+/* *flag (device int) := 1 if some element of x [rows][ld] is not exactly representable in bf16, else 0. */
+int kurbm_bf16_exact(kurbm_ctx* ctx, const float* x, int rows, int cols, int ld, int* flag,
+                     kurbm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

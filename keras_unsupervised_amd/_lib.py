@@ -62,6 +62,12 @@ SIGNATURES = {
     "kurbm_bf16_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "kurbm_cd_step_bf16": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _OP, _i, _vp, _sz, _vp]),
     "kurbm_half_step_bf16": (_i, [_vp, _PP, _vp, _sz, _i, _vp, _i, _i, _i, _i, _RP, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "kurbm_x3_mirror_bytes": (_sz, [_vp, _i, _i]),
+    "kurbm_x3_mirror_refresh": (_i, [_vp, _PP, _vp, _sz, _vp]),
+    "kurbm_x3_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
+    "kurbm_cd_step_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _vp, _sz, _vp]),
+    "kurbm_half_step_x3": (_i, [_vp, _PP, _vp, _sz, _i, _vp, _i, _i, _i, _i, _i, _RP, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "kurbm_bf16_exact": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

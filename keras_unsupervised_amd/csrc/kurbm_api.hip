@@ -508,18 +508,24 @@ void kurbm_debug_set_off(int mask) { set_debug_off(mask); }
 }  // extern "C"
 
 // ======================================================================================
-// bf16 variant (kurbm_bf16.hip): mirrors, workspace, launch sequences
+// bf16-operand variants (kurbm_bf16.hip): mirrors, workspace, launch sequences
+//   pieces = 1  "bf16": operands rounded to bf16 (BASELINE.json config 5)
+//   pieces = 3  "x3":   every fp32 operand carried EXACTLY as three bf16 pieces (hi + mid + lo), one
+//                       k-segment of the NT GEMM per pair of pieces; 0/1 samples are a single piece
 // ======================================================================================
-struct Mirror { uint16_t *Wb, *Wtb; int Kh, Kv; size_t bytes; };
+struct Mirror { uint16_t *Wb, *Wtb; int Kh, Kv, pieces; size_t planeW, planeWt, bytes; };
 
-static Mirror carve_mirror(void* base, int n_vis, int n_hid) {
+static Mirror carve_mirror(void* base, int n_vis, int n_hid, int pieces) {
     Mirror m;
+    m.pieces = pieces;
     m.Kh = round_up(n_hid, 128);   // k extent of W  [n_vis][Kh]   (B operand of h->v)
     m.Kv = round_up(n_vis, 128);   // k extent of Wt [n_hid][Kv]   (B operand of v->h)
+    m.planeW = (size_t)n_vis * m.Kh;
+    m.planeWt = (size_t)n_hid * m.Kv;
     char* b = static_cast<char*>(base);
     size_t off = 0;
-    m.Wb = reinterpret_cast<uint16_t*>(b + off);  off = align_up(off + (size_t)n_vis * m.Kh * 2);
-    m.Wtb = reinterpret_cast<uint16_t*>(b + off); off = align_up(off + (size_t)n_hid * m.Kv * 2);
+    m.Wb = reinterpret_cast<uint16_t*>(b + off);  off = align_up(off + pieces * m.planeW * 2);
+    m.Wtb = reinterpret_cast<uint16_t*>(b + off); off = align_up(off + pieces * m.planeWt * 2);
     m.bytes = off;
     return m;
 }
@@ -528,18 +534,19 @@ struct WorkspaceB {
     uint16_t *vb, *vbT, *hb, *hbT, *v2b, *v2bT, *h2b, *hnT, *cb;
     float *part_h, *part_v, *slab, *tmp32;
     int Kv, Kh, Kb, ldh32, ldv32, max_row_tiles;
+    size_t planeV, planeVT, planeHT;   // distance between the pieces of v_pos (both images) and of h_neg^T
     size_t slab_stride, bytes;
 };
 
 struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_split, ld_slab; };
 
-static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid) {
+static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg) {
     OuterPlanB pl;
     pl.gm = ceil_div(n_vis, 128);
     pl.gn = ceil_div(n_hid, 128);
     pl.nkt = round_up(rows, 128) / 128;
-    pl.kt_total = 2 * pl.nkt;
-    int s = (2 * ctx->ncu) / (pl.gm * pl.gn);
+    pl.kt_total = nseg * pl.nkt;
+    int s = env_int("KURBM_BF16_SPLIT", (2 * ctx->ncu) / (pl.gm * pl.gn));
     if (s < 1) s = 1;
     if (s > pl.kt_total) s = pl.kt_total;
     pl.nsplit_bound = s;
@@ -549,7 +556,7 @@ static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int
     return pl;
 }
 
-static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_vis, int n_hid) {
+static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_vis, int n_hid, int pieces, int v_pieces) {
     WorkspaceB w;
     w.Kv = round_up(n_vis, 128);
     w.Kh = round_up(n_hid, 128);
@@ -557,18 +564,21 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.ldh32 = round_up(n_hid, 4);
     w.ldv32 = round_up(n_vis, 4);
     w.max_row_tiles = ceil_div(rows, 128);
-    const OuterPlanB pl = plan_outer_bf16(ctx, rows, n_vis, n_hid);
+    w.planeV = (size_t)w.Kb * w.Kv;
+    w.planeVT = (size_t)n_vis * w.Kb;
+    w.planeHT = (size_t)n_hid * w.Kb;
+    const OuterPlanB pl = plan_outer_bf16(ctx, rows, n_vis, n_hid, v_pieces + pieces);
     w.slab_stride = (size_t)n_vis * pl.ld_slab;
     char* b = static_cast<char*>(base);
     size_t off = 0;
     auto take16 = [&](size_t n) { uint16_t* p = reinterpret_cast<uint16_t*>(b + off); off = align_up(off + n * 2); return p; };
     auto take32 = [&](size_t n) { float* p = reinterpret_cast<float*>(b + off); off = align_up(off + n * 4); return p; };
-    w.vb = take16((size_t)w.Kb * w.Kv);    w.vbT = take16((size_t)n_vis * w.Kb);     // v_pos, both orientations
+    w.vb = take16(v_pieces * w.planeV);    w.vbT = take16(v_pieces * w.planeVT);     // v_pos, both orientations
     w.hb = take16((size_t)w.Kb * w.Kh);    w.hbT = take16((size_t)n_hid * w.Kb);     // h_pos
     w.v2b = take16((size_t)w.Kb * w.Kv);   w.v2bT = take16((size_t)n_vis * w.Kb);    // v_t / v_neg
     w.h2b = take16((size_t)w.Kb * w.Kh);                                             // h_t (k > 1, chain start)
-    w.hnT = take16((size_t)n_hid * w.Kb);                                            // h_neg probabilities, transposed
-    w.cb = take16((size_t)w.Kb * w.Kv);                                              // persistent chain as bf16
+    w.hnT = take16(pieces * w.planeHT);                                              // h_neg probabilities, transposed
+    w.cb = take16(v_pieces * w.planeV);                                              // persistent chain as bf16
     w.part_h = take32((size_t)w.max_row_tiles * w.ldh32);
     w.part_v = take32((size_t)w.max_row_tiles * w.ldv32);
     w.slab = take32(w.slab_stride * pl.nsplit_bound);
@@ -577,71 +587,88 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     return w;
 }
 
-// one bf16 half step: A [rows][lda] bf16 (k padded), weights from the mirror
+static inline uint32_t inv_of(int nkt) { return nkt > 1 ? (uint32_t)(0x100000000ull / (unsigned)nkt) + 1u : 0u; }
+
+// segment list of a product (a_pieces of A) x (b_pieces of B): all pairs when one side is a single
+// piece; otherwise the pairs with ia + ib <= 2 (the dropped ones are below 2^-24 of the product),
+// or all nine with KURBM_X3_FULL=1
+static int pair_codes(int a_pieces, int b_pieces, unsigned set, unsigned long long* codes, int nseg) {
+    const int maxsum = (a_pieces > 1 && b_pieces > 1 && !env_int("KURBM_X3_FULL", 0)) ? 2 : 4;
+    for (int ia = 0; ia < a_pieces; ++ia)
+        for (int ib = 0; ib < b_pieces; ++ib)
+            if (ia + ib <= maxsum) {
+                *codes |= (unsigned long long)((unsigned)ia | ((unsigned)ib << 2) | (set << 4)) << (5 * nseg);
+                ++nseg;
+            }
+    return nseg;
+}
+
+// optional outputs and side products of a bf16 half step
+struct HalfOutB {
+    uint16_t* out = nullptr; int ldo = 0;                 // bf16 value plane, row-major
+    uint16_t* outT = nullptr; int ldoT = 0;               // ... transposed
+    int outT_pieces = 1; size_t outT_plane = 0;
+    float* out_f32 = nullptr; float* prob_f32 = nullptr; float* out_u = nullptr; int ldo32 = 0;
+    const float* ref32 = nullptr; int ldref32 = 0;        // column partials of (ref - value)
+    const uint16_t* ref16 = nullptr; int ldref16 = 0;
+    float* colpart = nullptr; int ld_colpart = 0;
+    int* grid_m_out = nullptr;
+};
+
+// one half step: A [rows][lda] bf16 in a_pieces pieces (k padded), weights from the mirror
 static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const Mirror& m, const uint16_t* A, int lda,
-                       int rows, int act, int noise, const RngArgs* rng, uint16_t* out, int ldo, uint16_t* outT, int ldoT,
-                       float* out_f32, float* prob_f32, float* out_u, int ldo32, const float* ref32, int ldref32,
-                       const uint16_t* ref16, int ldref16, float* colpart, int ld_colpart, int* grid_m_out, hipStream_t st) {
+                       int a_pieces, size_t a_plane, int rows, int act, int noise, const RngArgs* rng, const HalfOutB& o,
+                       hipStream_t st) {
     GemmArgsB g;
     memset(&g, 0, sizeof g);
     const bool vh = (layout == LAYOUT_VH);
-    g.A0 = A; g.lda = lda;
-    g.B0 = vh ? m.Wtb : m.Wb; g.ldb = vh ? m.Kv : m.Kh;
+    g.A0 = A; g.lda = lda; g.a_plane0 = a_plane;
+    g.B0 = vh ? m.Wtb : m.Wb; g.ldb = vh ? m.Kv : m.Kh; g.b_plane0 = vh ? m.planeWt : m.planeW;
     g.M = rows; g.N = vh ? p->n_hid : p->n_vis; g.K = vh ? m.Kv : m.Kh;
-    g.nseg = 1; g.nkt = g.K / 128; g.kt_total = g.nkt; g.kt_per_split = g.nkt; g.nsplit = 1;
+    g.nseg = pair_codes(a_pieces, m.pieces, 0u, &g.seg_codes, 0);
     // tile choice: 128x128 when that already gives every CU two workgroups; the wave-specialised
     // 128x128 kernel (4 MFMA + 4 loader waves, one workgroup per CU) when there is about one tile per
     // CU; 128x64 tiles (more, smaller workgroups) for small grids
     const int tiles128 = ceil_div(rows, 128) * ceil_div(g.N, 128);
     g.cfg = env_int("KURBM_BF16_CFG", tiles128 >= 2 * ctx->ncu ? 0 : (2 * tiles128 >= ctx->ncu ? 2 : 1));
     g.grid_m = ceil_div(rows, 128); g.grid_n = ceil_div(g.N, 128) * (g.cfg == 1 ? 2 : 1);   // covers the 128-padded row
-    if (g.cfg == 1) { g.nkt = g.K / 64; g.kt_total = g.nkt; g.kt_per_split = g.nkt; }
+    g.nkt = g.K / (g.cfg == 1 ? 64 : 128);
+    g.inv_nkt = inv_of(g.nkt);
+    g.kt_total = g.nseg * g.nkt; g.kt_per_split = g.kt_total; g.nsplit = 1;
     g.bias = vh ? p->b_h : p->b_v;
     g.act = act; g.noise = noise;
     if (rng) g.rng = *rng;
-    g.out = out; g.ldo = ldo; g.ldo_cols = out ? ldo : g.N;
-    g.outT = outT; g.ldoT = ldoT;
-    g.out_f32 = out_f32; g.prob_f32 = prob_f32; g.out_u = out_u; g.ldo32 = ldo32;
-    g.ref32 = ref32; g.ldref32 = ldref32; g.ref16 = ref16; g.ldref16 = ldref16;
-    g.colpart = colpart; g.ld_colpart = ld_colpart;
+    g.out = o.out; g.ldo = o.ldo; g.ldo_cols = o.out ? o.ldo : g.N;
+    g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
+    g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
+    g.ref32 = o.ref32; g.ldref32 = o.ldref32; g.ref16 = o.ref16; g.ldref16 = o.ldref16;
+    g.colpart = o.colpart; g.ld_colpart = o.ld_colpart;
     g.m_fastest = (g.grid_m < g.grid_n) ? 1 : 0;
-    if (grid_m_out) *grid_m_out = g.grid_m;
+    if (o.grid_m_out) *o.grid_m_out = g.grid_m;
     HIP_TRY(launch_gemm_bf16(EPI_HALFSTEP, g, st));
     return KURBM_OK;
 }
 
-extern "C" {
-
-size_t kurbm_bf16_mirror_bytes(kurbm_ctx* ctx, int n_vis, int n_hid) {
-    if (!ctx || n_vis <= 0 || n_hid <= 0) return 0;
-    return carve_mirror(nullptr, n_vis, n_hid).bytes;
-}
-
-int kurbm_bf16_mirror_refresh(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+static int mirror_refresh_any(kurbm_ctx* ctx, int pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                               kurbm_stream_t stream) {
     if (!ctx) return fail(KURBM_ERR_ARG, "ctx is null");
     if (int e = check_params(p)) return e;
     if (!mirror || !aligned16(mirror)) return fail(KURBM_ERR_ARG, "mirror is null or misaligned");
-    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid);
+    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, pieces);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
-    HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.Kh, p->n_vis, m.Wtb, m.Kv, p->n_hid,
-                               static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.Kh, p->n_vis, m.Wtb, m.Kv, p->n_hid, pieces,
+                               m.planeW, m.planeWt, static_cast<hipStream_t>(stream)));
     return KURBM_OK;
 }
 
-size_t kurbm_bf16_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int k) {
-    (void)k;
-    if (!ctx || rows <= 0 || n_vis <= 0 || n_hid <= 0) return 0;
-    return carve_bf16(ctx, nullptr, rows, n_vis, n_hid).bytes;
-}
-
-int kurbm_half_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, int dir,
-                         const float* in, int rows, int ld_in, int act, int noise, const kurbm_rng* rng,
+static int half_step_any(kurbm_ctx* ctx, int pieces, int in_pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                         int dir, const float* in, int rows, int ld_in, int act, int noise, const kurbm_rng* rng,
                          float* out_sample, float* out_prob, float* out_u, int ld_out, void* workspace,
                          size_t workspace_bytes, kurbm_stream_t stream) {
     if (!ctx) return fail(KURBM_ERR_ARG, "ctx is null");
     if (int e = check_params(p)) return e;
     if (dir != 0 && dir != 1) return fail(KURBM_ERR_ARG, "dir must be 0 (v->h) or 1 (h->v)");
+    if (in_pieces != 1 && in_pieces != 3) return fail(KURBM_ERR_ARG, "in_pieces must be 1 or 3");
     const int K = dir == 0 ? p->n_vis : p->n_hid, N = dir == 0 ? p->n_hid : p->n_vis;
     if (rows <= 0 || bad_matrix(in, ld_in, K)) return fail(KURBM_ERR_ARG, "input: null, misaligned, ld %% 4 != 0 or ld < columns");
     if (noise != NOISE_NONE && (!rng || (rng->row0 & 3))) return fail(KURBM_ERR_ARG, "rng missing or row0 not a multiple of 4");
@@ -649,24 +676,28 @@ int kurbm_half_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
     if (ld_out % 4 != 0 || ld_out < N) return fail(KURBM_ERR_ARG, "ld_out %% 4 != 0 or ld_out < columns");
     if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid);
+    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, pieces);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small");
-    const WorkspaceB w = carve_bf16(ctx, workspace, rows, p->n_vis, p->n_hid);
-    if (w.bytes > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
-    uint16_t* Ab = dir == 0 ? w.vb : w.hb;
-    const int lda = dir == 0 ? w.Kv : w.Kh;
-    HIP_TRY(launch_f32_to_bf16(in, rows, K, ld_in, Ab, lda, w.Kb, nullptr, 0, 0, st));
+    // the input plane is staged in the larger of the two row-major buffers' shapes: use a private carve
+    const int Kp = round_up(K, 128), Kb = round_up(rows, 128);
+    const size_t plane = (size_t)Kb * Kp;
+    const size_t need = align_up(in_pieces * plane * 2);
+    if (need > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    uint16_t* Ab = static_cast<uint16_t*>(workspace);
+    HIP_TRY(launch_f32_to_bf16(in, rows, K, ld_in, Ab, Kp, Kb, nullptr, 0, 0, in_pieces, plane, 0, st));
     RngArgs r;
     if (rng) r = make_rng(rng->seed, rng->row0, rng->stream_id, rng->step);
-    float* val = (noise == NOISE_NONE) ? (out_prob ? out_prob : out_sample) : out_sample;
-    float* prob = (noise == NOISE_NONE) ? nullptr : out_prob;
-    return half_step_b(ctx, dir == 0 ? LAYOUT_VH : LAYOUT_HV, p, m, Ab, lda, rows, act, noise, rng ? &r : nullptr, nullptr, 0,
-                       nullptr, 0, val, prob, out_u, ld_out, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, st);
+    HalfOutB o;
+    o.out_f32 = (noise == NOISE_NONE) ? (out_prob ? out_prob : out_sample) : out_sample;
+    o.prob_f32 = (noise == NOISE_NONE) ? nullptr : out_prob;
+    o.out_u = out_u; o.ldo32 = ld_out;
+    return half_step_b(ctx, dir == 0 ? LAYOUT_VH : LAYOUT_HV, p, m, Ab, Kp, in_pieces, plane, rows, act, noise,
+                       rng ? &r : nullptr, o, st);
 }
 
-int kurbm_cd_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
-                       int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace, size_t workspace_bytes,
-                       kurbm_stream_t stream) {
+static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                       const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace,
+                       size_t workspace_bytes, kurbm_stream_t stream) {
     if (!ctx || !o) return fail(KURBM_ERR_ARG, "null argument");
     if (int e = check_params(p)) return e;
     if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
@@ -674,13 +705,16 @@ int kurbm_cd_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size
     if (o->k < 1 || o->k > 15) return fail(KURBM_ERR_ARG, "k must be in [1, 15]");
     if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN)
         return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
+    if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1 or 3");
+    if (pieces == 3 && o->mode != KURBM_MODE_VISIBLE_BERNOULLI)
+        return fail(KURBM_ERR_ARG, "the x3 path covers MODE_VISIBLE_BERNOULLI only (real-valued negative visibles: use kurbm_cd_step)");
     if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
     if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
     if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid);
+    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, pieces);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
-    const WorkspaceB w = carve_bf16(ctx, workspace, rows, p->n_vis, p->n_hid);
+    const WorkspaceB w = carve_bf16(ctx, workspace, rows, p->n_vis, p->n_hid, pieces, v_pieces);
     if (w.bytes > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
 
     const bool gauss = (o->mode == KURBM_MODE_VISIBLE_GAUSSIAN);
@@ -691,52 +725,72 @@ int kurbm_cd_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size
     const bool need_w = (which & 1) || o->delta_out;
     int e;
 
-    // v_pos -> bf16, row-major (A of the v->h step) and transposed (statistics)
-    HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Kv, w.Kb, w.vbT, w.Kb, p->n_vis, st));
+    // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
+    HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Kv, w.Kb, w.vbT, w.Kb, p->n_vis, v_pieces, w.planeV,
+                               w.planeVT, st));
     // h_pos ~ p(h | v_pos)                                          rbm.py:120
     RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
-    if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Kv, rows, act_h, NOISE_BERNOULLI, &r, w.hb, w.Kh, w.hbT, w.Kb, nullptr,
-                         nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, st)))
-        return e;
+    {
+        HalfOutB ho;
+        ho.out = w.hb; ho.ldo = w.Kh; ho.outT = w.hbT; ho.ldoT = w.Kb;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Kv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
+    }
     const uint16_t* h_cur = w.hb;
     if (o->v_chain) {   // persistent chain: negative phase starts from the stored fantasy particles
-        HIP_TRY(launch_f32_to_bf16(o->v_chain, rows, p->n_vis, ldv, w.cb, w.Kv, w.Kb, nullptr, 0, 0, st));
+        HIP_TRY(launch_f32_to_bf16(o->v_chain, rows, p->n_vis, ldv, w.cb, w.Kv, w.Kb, nullptr, 0, 0, v_pieces, w.planeV, 0, st));
         r = make_rng(o->seed, o->row0, base + 32u, o->step);
-        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.cb, w.Kv, rows, act_h, NOISE_BERNOULLI, &r, w.h2b, w.Kh, nullptr, 0, nullptr,
-                             nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, st)))
-            return e;
+        HalfOutB ho;
+        ho.out = w.h2b; ho.ldo = w.Kh;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.cb, w.Kv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
         h_cur = w.h2b;
     }
     int gm_v = 0, gm_h = 0;
     for (int t = 1; t <= o->k; ++t) {
         const bool last = (t == o->k);
         r = make_rng(o->seed, o->row0, base + 2u * t - 1u, o->step);      // v_t ~ p(v | h_{t-1})   rbm.py:121-123
-        if ((e = half_step_b(ctx, LAYOUT_HV, p, m, h_cur, w.Kh, rows, act_v, noise_v, &r, w.v2b, w.Kv, last ? w.v2bT : nullptr,
-                             w.Kb, (last && o->v_chain) ? o->v_chain : nullptr, nullptr, nullptr, ldv,
-                             last ? v_batch : nullptr, ldv, nullptr, 0, w.part_v, w.ldv32, last ? &gm_v : nullptr, st)))
-            return e;
+        {
+            HalfOutB ho;
+            ho.out = w.v2b; ho.ldo = w.Kv;
+            if (last) {
+                ho.outT = w.v2bT; ho.ldoT = w.Kb;
+                ho.out_f32 = o->v_chain; ho.ldo32 = ldv;
+                ho.ref32 = v_batch; ho.ldref32 = ldv;
+                ho.grid_m_out = &gm_v;
+            }
+            ho.colpart = w.part_v; ho.ld_colpart = w.ldv32;
+            if ((e = half_step_b(ctx, LAYOUT_HV, p, m, h_cur, w.Kh, 1, 0, rows, act_v, noise_v, &r, ho, st))) return e;
+        }
         if (!last) {
             r = make_rng(o->seed, o->row0, base + 2u * t, o->step);
-            if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Kv, rows, act_h, NOISE_BERNOULLI, &r, w.h2b, w.Kh, nullptr, 0,
-                                 nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, st)))
-                return e;
+            HalfOutB ho;
+            ho.out = w.h2b; ho.ldo = w.Kh;
+            if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Kv, 1, 0, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
             h_cur = w.h2b;
         }
     }
     // h_neg = sigmoid(v_neg.W + b_h), probabilities (rbm.py:124): only its transposed image is needed
-    if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Kv, rows, ACT_SIGMOID, NOISE_NONE, nullptr, nullptr, 0, w.hnT, w.Kb, nullptr,
-                         nullptr, nullptr, 0, nullptr, 0, w.hb, w.Kh, w.part_h, w.ldh32, &gm_h, st)))
-        return e;
+    {
+        HalfOutB ho;
+        ho.outT = w.hnT; ho.ldoT = w.Kb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT;
+        ho.ref16 = w.hb; ho.ldref16 = w.Kh;
+        ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.grid_m_out = &gm_h;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Kv, 1, 0, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st))) return e;
+    }
 
-    // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch
-    const OuterPlanB pl = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid);
+    // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
+    // segments: (piece of v_pos) x h_pos, then v_neg x (piece of h_neg), negated
+    const OuterPlanB pl = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, v_pieces + pieces);
     if (need_w) {
         GemmArgsB g;
         memset(&g, 0, sizeof g);
-        g.A0 = w.vbT; g.A1 = w.v2bT; g.lda = w.Kb;
-        g.B0 = w.hbT; g.B1 = w.hnT; g.ldb = w.Kb;
+        g.A0 = w.vbT; g.a_plane0 = w.planeVT; g.B0 = w.hbT;
+        g.A1 = w.v2bT; g.B1 = w.hnT; g.b_plane1 = w.planeHT;
+        g.lda = w.Kb; g.ldb = w.Kb;
         g.M = p->n_vis; g.N = p->n_hid; g.K = w.Kb;
-        g.nseg = 2; g.nkt = pl.nkt; g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
+        g.nseg = pair_codes(v_pieces, 1, 0u, &g.seg_codes, 0);
+        g.nseg = pair_codes(1, pieces, 1u, &g.seg_codes, g.nseg);
+        g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
+        g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
         g.grid_m = pl.gm; g.grid_n = pl.gn;
         g.slab = w.slab; g.slab_stride = w.slab_stride; g.ld_slab = pl.ld_slab;
         HIP_TRY(launch_gemm_bf16(EPI_SLAB, g, st));
@@ -757,8 +811,73 @@ int kurbm_cd_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size
     a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
     a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
     HIP_TRY(launch_reduce_apply(a, st));
-    if (a.W)   // the fp32 master moved: re-quantise both mirrors
-        HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.Kh, p->n_vis, m.Wtb, m.Kv, p->n_hid, st));
+    if (a.W)   // the fp32 master moved: re-derive both mirrors
+        HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.Kh, p->n_vis, m.Wtb, m.Kv, p->n_hid, pieces,
+                                   m.planeW, m.planeWt, st));
+    return KURBM_OK;
+}
+
+extern "C" {
+
+size_t kurbm_bf16_mirror_bytes(kurbm_ctx* ctx, int n_vis, int n_hid) {
+    if (!ctx || n_vis <= 0 || n_hid <= 0) return 0;
+    return carve_mirror(nullptr, n_vis, n_hid, 1).bytes;
+}
+size_t kurbm_x3_mirror_bytes(kurbm_ctx* ctx, int n_vis, int n_hid) {
+    if (!ctx || n_vis <= 0 || n_hid <= 0) return 0;
+    return carve_mirror(nullptr, n_vis, n_hid, 3).bytes;
+}
+
+int kurbm_bf16_mirror_refresh(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, kurbm_stream_t stream) {
+    return mirror_refresh_any(ctx, 1, p, mirror, mirror_bytes, stream);
+}
+int kurbm_x3_mirror_refresh(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, kurbm_stream_t stream) {
+    return mirror_refresh_any(ctx, 3, p, mirror, mirror_bytes, stream);
+}
+
+size_t kurbm_bf16_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int k) {
+    (void)k;
+    if (!ctx || rows <= 0 || n_vis <= 0 || n_hid <= 0) return 0;
+    return carve_bf16(ctx, nullptr, rows, n_vis, n_hid, 1, 1).bytes;
+}
+size_t kurbm_x3_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int k, int v_pieces) {
+    (void)k;
+    if (!ctx || rows <= 0 || n_vis <= 0 || n_hid <= 0 || (v_pieces != 1 && v_pieces != 3)) return 0;
+    return carve_bf16(ctx, nullptr, rows, n_vis, n_hid, 3, v_pieces).bytes;
+}
+
+int kurbm_half_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, int dir,
+                         const float* in, int rows, int ld_in, int act, int noise, const kurbm_rng* rng,
+                         float* out_sample, float* out_prob, float* out_u, int ld_out, void* workspace,
+                         size_t workspace_bytes, kurbm_stream_t stream) {
+    return half_step_any(ctx, 1, 1, p, mirror, mirror_bytes, dir, in, rows, ld_in, act, noise, rng, out_sample, out_prob,
+                         out_u, ld_out, workspace, workspace_bytes, stream);
+}
+int kurbm_half_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, int dir,
+                       const float* in, int in_pieces, int rows, int ld_in, int act, int noise, const kurbm_rng* rng,
+                       float* out_sample, float* out_prob, float* out_u, int ld_out, void* workspace,
+                       size_t workspace_bytes, kurbm_stream_t stream) {
+    return half_step_any(ctx, 3, in_pieces, p, mirror, mirror_bytes, dir, in, rows, ld_in, act, noise, rng, out_sample,
+                         out_prob, out_u, ld_out, workspace, workspace_bytes, stream);
+}
+
+int kurbm_cd_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
+                       int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace, size_t workspace_bytes,
+                       kurbm_stream_t stream) {
+    return cd_step_any(ctx, 1, 1, p, mirror, mirror_bytes, v_batch, rows, ldv, o, which, workspace, workspace_bytes, stream);
+}
+int kurbm_cd_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
+                     int v_pieces, int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace,
+                     size_t workspace_bytes, kurbm_stream_t stream) {
+    return cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, which, workspace, workspace_bytes, stream);
+}
+
+int kurbm_bf16_exact(kurbm_ctx* ctx, const float* x, int rows, int cols, int ld, int* flag, kurbm_stream_t stream) {
+    if (!ctx || !flag) return fail(KURBM_ERR_ARG, "null argument");
+    if (rows <= 0 || cols <= 0 || bad_matrix(x, ld, cols)) return fail(KURBM_ERR_ARG, "x: null, misaligned, ld %% 4 != 0 or ld < cols");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
+    HIP_TRY(launch_bf16_exact_check(x, rows, cols, ld, flag, st));
     return KURBM_OK;
 }
 

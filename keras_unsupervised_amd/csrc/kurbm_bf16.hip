@@ -36,9 +36,11 @@ constexpr int NTH = 256;
 // ------------------------------------------------------------------------------------
 // One 32 x 32 tile per workgroup through LDS; out-of-range source elements read as zero, so the
 // k padding of both mirrors is written here and nowhere else.
+// pieces = 3 writes the exact split x = hi + mid + lo (bf16_piece_bits) as three planes.
 __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ in, int rows, int cols, int ld_in,
                                                      uint16_t* __restrict__ out, int ldo, int out_rows,
-                                                     uint16_t* __restrict__ outT, int ldoT, int outT_rows) {
+                                                     uint16_t* __restrict__ outT, int ldoT, int outT_rows,
+                                                     int pieces, size_t out_plane, size_t outT_plane) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -47,15 +49,46 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
         const int r = r0 + ty + 8 * j, c = c0 + tx;
         const float v = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : 0.f;
         tile[ty + 8 * j][tx] = v;
-        if (out && r < out_rows && c < ldo) out[(size_t)r * ldo + c] = (uint16_t)f32_to_bf16_bits(v);
+        if (out && r < out_rows && c < ldo) {
+            const size_t o = (size_t)r * ldo + c;
+            out[o] = (uint16_t)bf16_piece_bits(v, 0);
+            if (pieces == 3) {
+                out[o + out_plane] = (uint16_t)bf16_piece_bits(v, 1);
+                out[o + 2 * out_plane] = (uint16_t)bf16_piece_bits(v, 2);
+            }
+        }
     }
     if (!outT) return;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = c0 + ty + 8 * j, r = r0 + tx;   // outT[c][r]
-        if (c < outT_rows && r < ldoT) outT[(size_t)c * ldoT + r] = (uint16_t)f32_to_bf16_bits(tile[tx][ty + 8 * j]);
+        if (c < outT_rows && r < ldoT) {
+            const float v = tile[tx][ty + 8 * j];
+            const size_t o = (size_t)c * ldoT + r;
+            outT[o] = (uint16_t)bf16_piece_bits(v, 0);
+            if (pieces == 3) {
+                outT[o + outT_plane] = (uint16_t)bf16_piece_bits(v, 1);
+                outT[o + 2 * outT_plane] = (uint16_t)bf16_piece_bits(v, 2);
+            }
+        }
     }
+}
+
+// flag := 1 if some element of `in` is not exactly representable in bf16 (the caller zeroes it)
+__global__ __launch_bounds__(256) void k_bf16_exact_check(const float* __restrict__ in, int rows, int cols, int ld_in,
+                                                          int* __restrict__ flag) {
+    const int c4 = cols >> 2;   // ld % 4 == 0 and 16-B aligned rows: whole float4s, then the tail
+    bool bad = false;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* row = in + (size_t)r * ld_in;
+        for (int c = threadIdx.x; c < c4; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * c);
+            bad |= ((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) & 0xFFFFu) != 0u;
+        }
+        for (int c = 4 * c4 + threadIdx.x; c < cols; c += 256) bad |= (__float_as_uint(row[c]) & 0xFFFFu) != 0u;
+    }
+    if (bad) *flag = 1;
 }
 
 // ------------------------------------------------------------------------------------
@@ -139,11 +172,13 @@ __global__ __launch_bounds__(WS ? 2 * NTH : NTH) void k_gemm_bf16(GemmArgsB g) {
 
     auto tile_of = [&](int t, const uint16_t*& oa, const uint16_t*& ob, uint32_t& flip) {
         t = t < t_end ? t : t_end - 1;
-        const int seg = (t >= g.nkt) ? 1 : 0;
+        const int seg = g.inv_nkt ? (int)__umulhi((uint32_t)t, g.inv_nkt) : t;   // inv_nkt == 0: one k-tile per segment
+        const uint32_t code = (uint32_t)(g.seg_codes >> (5 * seg)) & 31u;
+        const bool neg = (code & 16u) != 0u;
         const size_t k0 = (size_t)(t - seg * g.nkt) * BKB;
-        oa = (seg ? g.A1 : g.A0) + k0;
-        ob = (seg ? g.B1 : g.B0) + k0;
-        flip = seg ? 0x80008000u : 0u;   // sign bits of a bf16 pair: segment 1 enters negated
+        oa = (neg ? g.A1 : g.A0) + (code & 3u) * (neg ? g.a_plane1 : g.a_plane0) + k0;
+        ob = (neg ? g.B1 : g.B0) + ((code >> 2) & 3u) * (neg ? g.b_plane1 : g.b_plane0) + k0;
+        flip = neg ? 0x80008000u : 0u;   // sign bits of a bf16 pair: set 1 enters negated
     };
     auto fetch = [&](Regs& R, int t) {
         const uint16_t *oa, *ob;
@@ -367,6 +402,7 @@ __global__ __launch_bounds__(WS ? 2 * NTH : NTH) void k_gemm_bf16(GemmArgsB g) {
 
     // registers -> patch; then (a) whole rows of the row-major planes, (b) whole rows of the
     // transposed bf16 plane, both 16 B per lane
+    const bool pieces3 = (g.outT_pieces == 3);
     auto flush = [&](const float (&val)[TM][TN][4], uint16_t* __restrict__ o16, uint16_t* __restrict__ o16T,
                      float* __restrict__ o32, bool diff) {
         __syncthreads();
@@ -424,10 +460,20 @@ __global__ __launch_bounds__(WS ? 2 * NTH : NTH) void k_gemm_bf16(GemmArgsB g) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (gb + e < g.M) ? patch[(8 * tc8 + e) * LDE + lcol] : 0.f;
-                    u32x4 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-                    pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
-                    *reinterpret_cast<u32x4*>(o16T + (size_t)gn * g.ldoT + gb) = pk;
+                    uint16_t* dst = o16T + (size_t)gn * g.ldoT + gb;
+                    const int np = pieces3 ? 3 : 1;
+                    for (int j = 0; j < np; ++j) {
+                        u32x4 pk;
+                        pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                        pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+                        *reinterpret_cast<u32x4*>(dst + j * g.outT_plane) = pk;
+                        if (j + 1 < np) {   // residual of the piece just written: exact in fp32
+                            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                v[e] -= bf16_bits_to_f32((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xFFFFu));
+                        }
+                    }
                 }
             }
         }
@@ -462,14 +508,20 @@ __global__ __launch_bounds__(WS ? 2 * NTH : NTH) void k_gemm_bf16(GemmArgsB g) {
 // launchers
 // ------------------------------------------------------------------------------------
 hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
-                              uint16_t* outT, int ldoT, int outT_rows, hipStream_t st) {
+                              uint16_t* outT, int ldoT, int outT_rows, int pieces, size_t out_plane, size_t outT_plane,
+                              hipStream_t st) {
     // cover the padded extents of whichever mirrors are requested
     int r_ext = rows, c_ext = cols;
     if (out) { if (out_rows > r_ext) r_ext = out_rows; if (ldo > c_ext) c_ext = ldo; }
     if (outT) { if (ldoT > r_ext) r_ext = ldoT; if (outT_rows > c_ext) c_ext = outT_rows; }
     dim3 grid((c_ext + 31) / 32, (r_ext + 31) / 32);
     hipLaunchKernelGGL(k_f32_to_bf16, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
-                       outT_rows);
+                       outT_rows, pieces, out_plane, outT_plane);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16_exact_check(const float* in, int rows, int cols, int ld_in, int* flag, hipStream_t st) {
+    hipLaunchKernelGGL(k_bf16_exact_check, dim3(rows < 1024 ? rows : 1024), dim3(256), 0, st, in, rows, cols, ld_in, flag);
     return hipGetLastError();
 }
 

@@ -50,4 +50,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
 }
 
+
+// Exact three-way split of an fp32 value into bf16 pieces, x == hi + mid + lo (round to nearest even at
+// every stage: the two residuals are exact in fp32 and the last one has at most 8 significant bits).
+// piece j of x, j = 0, 1, 2:
+__device__ __forceinline__ uint32_t bf16_piece_bits(float x, int j) {
+    uint32_t h = f32_to_bf16_bits(x);
+    if (j == 0) return h;
+    x -= bf16_bits_to_f32(h);
+    h = f32_to_bf16_bits(x);
+    if (j == 1) return h;
+    x -= bf16_bits_to_f32(h);
+    return f32_to_bf16_bits(x);
+}
+
 }  // namespace kurbm

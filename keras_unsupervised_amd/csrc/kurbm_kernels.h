@@ -102,12 +102,20 @@ struct FinishArgs {
     int rows, n_vis, ldv, ncol_tiles, ld_rowpart;
 };
 
-// bf16 NT GEMM (kurbm_bf16.hip): A [M][lda], B [N][ldb] bf16, k contiguous and zero-padded to 128
+// bf16 NT GEMM (kurbm_bf16.hip): A [M][lda], B [N][ldb] bf16, k contiguous and zero-padded to 128.
+// The k range is a list of up to MAX_SEG SEGMENTS of K elements each.  Segment s multiplies piece ia of
+// operand set `neg` of A with piece ib of the same set of B (pieces = the bf16 hi / mid / lo parts of an
+// fp32 plane, `*_plane` elements apart); set 1 enters negated (the negative phase of the statistics).
+// seg_codes packs one 5-bit code per segment: bits 0-1 ia, bits 2-3 ib, bit 4 set.
+constexpr int MAX_SEG = 12;
 struct GemmArgsB {
     const uint16_t* A0;
     const uint16_t* B0;
-    const uint16_t* A1;   // segment 1 enters negated (statistics GEMM)
+    const uint16_t* A1;
     const uint16_t* B1;
+    size_t a_plane0, b_plane0, a_plane1, b_plane1;
+    unsigned long long seg_codes;
+    uint32_t inv_nkt;     // floor(2^32 / nkt) + 1: segment of k-tile t = umulhi(t, inv_nkt)
     int lda, ldb;         // elements, multiples of 8
     int M, N, K;          // K per segment, multiple of 128
     int nseg, nkt, kt_total, kt_per_split, nsplit;
@@ -124,6 +132,8 @@ struct GemmArgsB {
     int ldo_cols;         // columns the row planes cover: ldo when `out` is set (pads are zeroed), else N
     uint16_t* outT;       // bf16 [N][ldoT]  the same plane transposed; nullable
     int ldoT;
+    int outT_pieces;      // 1: outT = round-to-nearest bf16; 3: exact hi / mid / lo pieces, outT_plane apart
+    size_t outT_plane;
     float* out_f32;       // fp32 copy of the value plane (persistent chain, tests); nullable
     float* prob_f32;      // fp32 probabilities next to a sampled plane (tests); nullable
     float* out_u;         // fp32 uniforms (tests); nullable
@@ -142,8 +152,11 @@ struct GemmArgsB {
 
 void tile_shape(int cfg, int* bm, int* bn);
 hipError_t launch_gemm_bf16(int epi, const GemmArgsB& g, hipStream_t st);
+// pieces = 1: round to nearest bf16; 3: exact split x = hi + mid + lo, piece j at out + j * out_plane
 hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
-                              uint16_t* outT, int ldoT, int outT_rows, hipStream_t st);
+                              uint16_t* outT, int ldoT, int outT_rows, int pieces, size_t out_plane, size_t outT_plane,
+                              hipStream_t st);
+hipError_t launch_bf16_exact_check(const float* in, int rows, int cols, int ld_in, int* flag, hipStream_t st);
 hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g, hipStream_t st);
 hipError_t launch_philox_uniform(float* out, int rows, int cols, int ld, const RngArgs& rng, hipStream_t st);
 hipError_t launch_reduce_apply(const ReduceArgs& a, hipStream_t st);

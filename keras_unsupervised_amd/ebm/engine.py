@@ -47,10 +47,11 @@ def resolve_device(device=None):
 class DeviceMatrix:
     """Row-major fp32 [rows, ld] matrix on the device, ld % 4 == 0, padding zero."""
 
-    __slots__ = ("t", "rows", "cols", "ld")
+    __slots__ = ("t", "rows", "cols", "ld", "bf16_exact")
 
     def __init__(self, t, rows, cols, ld):
         self.t, self.rows, self.cols, self.ld = t, rows, cols, ld
+        self.bf16_exact = None   # True / False once DeviceRBM.v_pieces() has looked (0/1 data is exact)
 
     @classmethod
     def zeros(cls, rows, cols, device):
@@ -107,10 +108,10 @@ class DeviceRBM:
         self._ws = None
         self._ws_rows = 0
         self.delta = None  # packed [V*H | H | V] sums, allocated on first use
-        self._mirror = None        # bf16 images of W in both orientations (compute_dtype='bf16')
-        self._mirror_stale = True
-        self._ws_b = None
-        self._ws_b_rows = 0
+        # bf16 images of W in both orientations, per number of pieces: 1 = rounded (compute 'bf16'),
+        # 3 = exact hi/mid/lo split (compute 'x3');  [tensor, stale]
+        self._mirrors = {}
+        self._ws_b = {}
 
     # -- plumbing -------------------------------------------------------------------
     def _stream(self):
@@ -131,27 +132,50 @@ class DeviceRBM:
             self.delta = torch.zeros(n, dtype=torch.float32, device=self.device)
         return self.delta
 
-    # -- bf16 mirrors (extension: bf16 operands, fp32 accumulate, fp32 master weights) -----
-    def mirror(self):
-        """The bf16 images of W, refreshed if the fp32 master was written behind the library's back."""
-        if self._mirror is None:
-            n = self.lib.kurbm_bf16_mirror_bytes(self.ctx.handle, self.n_vis, self.n_hid)
-            self._mirror = torch.zeros(n, dtype=torch.uint8, device=self.device)
-            self._mirror_stale = True
-        if self._mirror_stale:
-            check(self.lib.kurbm_bf16_mirror_refresh(self.ctx.handle, C.byref(self.params), self._mirror.data_ptr(),
-                                                     self._mirror.numel(), self._stream()))
-            self._mirror_stale = False
-        return self._mirror
+    # -- bf16 mirrors (fp32 master weights stay authoritative) --------------------------------
+    def _weights_written(self, kept=None):
+        """The fp32 W changed; every mirror except the one the library refreshed itself is stale."""
+        for pieces, m in self._mirrors.items():
+            if pieces != kept:
+                m[1] = True
 
-    def workspace_bf16(self, rows, k=1):
-        if self._ws_b is None or rows > self._ws_b_rows:
-            n = self.lib.kurbm_bf16_workspace_bytes(self.ctx.handle, rows, self.n_vis, self.n_hid, k)
+    def mirror(self, pieces=1):
+        """The bf16 images of W (1 piece: rounded; 3: exact split), refreshed if W was written elsewhere."""
+        m = self._mirrors.get(pieces)
+        fn_bytes = self.lib.kurbm_bf16_mirror_bytes if pieces == 1 else self.lib.kurbm_x3_mirror_bytes
+        fn_refresh = self.lib.kurbm_bf16_mirror_refresh if pieces == 1 else self.lib.kurbm_x3_mirror_refresh
+        if m is None:
+            n = fn_bytes(self.ctx.handle, self.n_vis, self.n_hid)
+            m = self._mirrors[pieces] = [torch.zeros(n, dtype=torch.uint8, device=self.device), True]
+        if m[1]:
+            check(fn_refresh(self.ctx.handle, C.byref(self.params), m[0].data_ptr(), m[0].numel(), self._stream()))
+            m[1] = False
+        return m[0]
+
+    def workspace_bf16(self, rows, k=1, pieces=1, v_pieces=1):
+        key = (pieces, v_pieces)
+        have = self._ws_b.get(key)
+        if have is None or rows > have[1]:
+            if pieces == 1:
+                n = self.lib.kurbm_bf16_workspace_bytes(self.ctx.handle, rows, self.n_vis, self.n_hid, k)
+            else:
+                n = self.lib.kurbm_x3_workspace_bytes(self.ctx.handle, rows, self.n_vis, self.n_hid, k, v_pieces)
             if n == 0:
-                raise _lib.KurbmError("kurbm_bf16_workspace_bytes failed")
-            self._ws_b = torch.zeros(n, dtype=torch.uint8, device=self.device)
-            self._ws_b_rows = rows
-        return self._ws_b
+                raise _lib.KurbmError("workspace size query failed")
+            have = self._ws_b[key] = (torch.zeros(n, dtype=torch.uint8, device=self.device), rows)
+        return have[0]
+
+    def v_pieces(self, v):
+        """1 if every element of DeviceMatrix v is exactly a bf16 value (0/1 data is), else 3.
+
+        Looked at once per matrix (one pass over it on the device, one 4-byte read back)."""
+        if v.bf16_exact is None:
+            with torch.cuda.device(self.device):
+                flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+                check(self.lib.kurbm_bf16_exact(self.ctx.handle, v.ptr(), max(v.rows, 1), v.cols, v.ld, flag.data_ptr(),
+                                                self._stream()))
+                v.bf16_exact = int(flag.item()) == 0
+        return 1 if v.bf16_exact else 3
 
     def get_weights(self):
         return self.W.to_numpy(), self.b_h.cpu().numpy(), self.b_v.cpu().numpy()
@@ -161,7 +185,7 @@ class DeviceRBM:
             W = np.asarray(W, dtype=np.float32)
             assert W.shape == (self.n_vis, self.n_hid)
             self.W.t[:, : self.n_hid].copy_(torch.from_numpy(np.ascontiguousarray(W)))
-            self._mirror_stale = True
+            self._weights_written()
         if b_h is not None:
             self.b_h.copy_(torch.from_numpy(np.ascontiguousarray(b_h, dtype=np.float32)))
         if b_v is not None:
@@ -193,22 +217,43 @@ class DeviceRBM:
         return out
 
     def cd_step(self, v, rows, row_start, lr, seed, step, k=1, mode=MODE_VISIBLE_BERNOULLI, chain=0,
-                which=WHICH_ALL, apply=True, emit_delta=False, v_chain=None, row0=0, v_chain_row=0, bf16=False):
-        """One CD-k update on rows [row_start, row_start+rows) of DeviceMatrix v."""
+                which=WHICH_ALL, apply=True, emit_delta=False, v_chain=None, row0=0, v_chain_row=0, bf16=False,
+                compute=None):
+        """One CD-k update on rows [row_start, row_start+rows) of DeviceMatrix v.
+
+        compute: 'fp32' (fp32 MFMA), 'x3' (fp32 values as exact bf16 triples on the bf16 MFMA),
+        'bf16' (operands rounded to bf16)."""
+        compute = compute or ("bf16" if bf16 else "fp32")
         with torch.cuda.device(self.device):
             opts = CdOpts(int(k), int(mode), float(lr), 1 if apply else 0,
                           self.delta_buffer().data_ptr() if emit_delta else None,
                           v_chain.ptr(v_chain_row) if v_chain is not None else None,
                           int(seed), int(row0), int(step) & 0xFFFFFFFF, int(chain))
-            if bf16:
-                mir, ws = self.mirror(), self.workspace_bf16(rows, k)
+            if compute == "bf16":
+                mir, ws = self.mirror(1), self.workspace_bf16(rows, k)
                 check(self.lib.kurbm_cd_step_bf16(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
                                                   v.ptr(row_start), rows, v.ld, C.byref(opts), int(which),
                                                   ws.data_ptr(), ws.numel(), self._stream()))
-                return
-            ws = self.workspace(rows, k)
-            check(self.lib.kurbm_cd_step(self.ctx.handle, C.byref(self.params), v.ptr(row_start), rows, v.ld,
-                                         C.byref(opts), int(which), ws.data_ptr(), ws.numel(), self._stream()))
+                if apply and (which & 1):
+                    self._weights_written(kept=1)
+            elif compute == "x3":
+                vp = self.v_pieces(v)
+                if v_chain is not None and vp == 1:
+                    vp = self.v_pieces(v_chain)
+                mir, ws = self.mirror(3), self.workspace_bf16(rows, k, 3, vp)
+                check(self.lib.kurbm_cd_step_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                                v.ptr(row_start), vp, rows, v.ld, C.byref(opts), int(which),
+                                                ws.data_ptr(), ws.numel(), self._stream()))
+                if apply and (which & 1):
+                    self._weights_written(kept=3)
+            elif compute == "fp32":
+                ws = self.workspace(rows, k)
+                check(self.lib.kurbm_cd_step(self.ctx.handle, C.byref(self.params), v.ptr(row_start), rows, v.ld,
+                                             C.byref(opts), int(which), ws.data_ptr(), ws.numel(), self._stream()))
+                if apply and (which & 1):
+                    self._weights_written()
+            else:
+                raise ValueError("compute must be 'fp32', 'x3' or 'bf16', got %r" % (compute,))
 
     def cd_epoch(self, v, n_rows, batch_size, lr, seed, step0, k=1, mode=MODE_VISIBLE_BERNOULLI, v_chain=None):
         """All batches of one epoch in ONE library call (fp32, fused updates, no score); returns #steps."""
@@ -220,21 +265,26 @@ class DeviceRBM:
                                         int(batch_size), C.byref(opts), ws.data_ptr(), ws.numel(), self._stream())
             if n < 0:
                 check(n)
-        self._mirror_stale = True
+        self._weights_written()
         return n
 
-    def half_step_bf16(self, direction, x, rows, act, noise, seed, stream_id, step, row0=0):
-        """Test hook: one half step with bf16 products; returns fp32 planes (sample, prob, u)."""
+    def half_step_bf16(self, direction, x, rows, act, noise, seed, stream_id, step, row0=0, pieces=1):
+        """Test hook: one half step with bf16 products (pieces=3: exact split); fp32 planes (sample, prob, u)."""
         n_out = self.n_hid if direction == "vh" else self.n_vis
         with torch.cuda.device(self.device):
-            mir, ws = self.mirror(), self.workspace_bf16(rows)
+            xp = self.v_pieces(x) if pieces == 3 else 1
+            mir, ws = self.mirror(pieces), self.workspace_bf16(rows, 1, pieces, xp if pieces == 3 else 1)
             out = {k: DeviceMatrix.zeros(rows, n_out, self.device) for k in ("sample", "prob", "u")}
             rng = Rng(int(seed), int(row0), int(stream_id) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF)
-            check(self.lib.kurbm_half_step_bf16(
-                self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), 0 if direction == "vh" else 1,
-                x.ptr(), rows, x.ld, act, noise, C.byref(rng), out["sample"].ptr() if noise else None,
-                out["prob"].ptr(), out["u"].ptr() if noise else None, round_up(n_out, 4), ws.data_ptr(), ws.numel(),
-                self._stream()))
+            tail = (act, noise, C.byref(rng), out["sample"].ptr() if noise else None, out["prob"].ptr(),
+                    out["u"].ptr() if noise else None, round_up(n_out, 4), ws.data_ptr(), ws.numel(), self._stream())
+            d = 0 if direction == "vh" else 1
+            if pieces == 3:
+                check(self.lib.kurbm_half_step_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), d,
+                                                  x.ptr(), xp, rows, x.ld, *tail))
+            else:
+                check(self.lib.kurbm_half_step_bf16(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), d,
+                                                    x.ptr(), rows, x.ld, *tail))
         return out
 
     def apply_delta(self, lr, which=WHICH_ALL, delta=None):
@@ -242,7 +292,7 @@ class DeviceRBM:
         with torch.cuda.device(self.device):
             check(self.lib.kurbm_apply_delta(self.ctx.handle, C.byref(self.params), delta.data_ptr(), float(lr),
                                              int(which), self._stream()))
-        self._mirror_stale = True
+        self._weights_written()
 
     def free_energy(self, v, rows, row_start=0):
         with torch.cuda.device(self.device):

@@ -57,9 +57,15 @@ class RBM(object):
             raise ValueError("update_mode must be one of %s" % (_UPDATE_MODES,))
         self.cd_k = int(opt("cd_k", 1))
         self.persistent = bool(opt("persistent", False))
-        self.compute_dtype = str(opt("compute_dtype", "fp32"))   # 'bf16': bf16 operands, fp32 accumulate (extension)
-        if self.compute_dtype not in ("fp32", "bf16"):
-            raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
+        # how the matrix products of fit() run (extension; storage, accumulation and results are fp32 in all):
+        #   'fp32'  fp32 MFMA               'x3'  fp32 values as exact bf16 triples on the bf16 MFMA (Bernoulli mode)
+        #   'bf16'  operands ROUNDED to bf16 (reduced precision, BASELINE.json config 5)
+        #   'auto'  'x3' where it applies, else 'fp32'
+        self.compute_dtype = str(opt("compute_dtype", "fp32"))
+        if self.compute_dtype not in ("fp32", "x3", "bf16", "auto"):
+            raise ValueError("compute_dtype must be 'fp32', 'x3', 'bf16' or 'auto'")
+        if self.compute_dtype == "x3" and mode != MODE_VISIBLE_BERNOULLI:
+            raise ValueError("compute_dtype='x3' covers MODE_VISIBLE_BERNOULLI only (use 'auto' or 'fp32')")
         self.list_returns = bool(kwargs.pop("ku_compat_list_returns", True))
         self._device_arg = kwargs.pop("device", None)
         self._init_weights = kwargs.pop("weights", None)
@@ -242,7 +248,7 @@ class RBM(object):
 
         # quiet single-GPU fused fp32 training: the whole batch loop of an epoch is one library call
         whole_epochs = (verbose != 1 and world == 1 and self.update_mode == "fused"
-                        and self.compute_dtype == "fp32")
+                        and self._compute() == "fp32")
         for epoch in range(int(self.hps["epochs"])):                              # rbm.py:113
             if verbose == 1:
                 print(epoch + 1, "/", self.hps["epochs"], " epochs", end="\r")   # rbm.py:115
@@ -265,17 +271,22 @@ class RBM(object):
                     print("\n{0:d}/{1:d}, score: {2:f}".format(i + 1, num_step, score))   # rbm.py:234
         return None
 
+    def _compute(self):
+        if self.compute_dtype == "auto":
+            return "x3" if self.mode == MODE_VISIBLE_BERNOULLI else "fp32"
+        return self.compute_dtype
+
     def _update_local(self, Vd, lo, rows, lr, step):
         d = self._dev
         if self.update_mode == "fused":
             d.cd_step(Vd, rows, lo, lr, self.seed, step, k=self.cd_k, mode=self.mode, chain=CHAIN_W,
-                      v_chain=self._v_chain if self.persistent else None, bf16=(self.compute_dtype == "bf16"))
+                      v_chain=self._v_chain if self.persistent else None, compute=self._compute())
         else:
             # the reference's three K.function calls: each its own chain, each seeing the variables
             # the previous call already updated (rbm.py:214-216)
             for chain, which in ((CHAIN_W, _lib.WHICH_W), (CHAIN_BH, _lib.WHICH_BH), (CHAIN_BV, _lib.WHICH_BV)):
                 d.cd_step(Vd, rows, lo, lr, self.seed, step, k=1, mode=self.mode, chain=chain, which=which,
-                          bf16=(self.compute_dtype == "bf16"))
+                          compute=self._compute())
 
     def _update_data_parallel(self, Vd, lo, rows, lr, step, rank, world):
         """Each rank: chain on its rows -> packed sums -> one all-reduce -> identical apply."""
@@ -288,7 +299,7 @@ class RBM(object):
             d.cd_step(Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,
                       chain=CHAIN_W, apply=False, emit_delta=True, row0=s_lo,
                       v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo,
-                      bf16=(self.compute_dtype == "bf16"))
+                      compute=self._compute())
         else:
             delta.zero_()
         dp.allreduce_sum_(delta)

@@ -555,3 +555,139 @@ def test_data_parallel_emulation_two_shards(gpu_device):
     for x, y, z in zip(a, b, ref):
         assert np.array_equal(x, y)
         assert np.max(np.abs(x - z)) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# x3: fp32 values as exact bf16 triples on the bf16 matrix cores -- held to the FP32 oracle and the
+# fp32 tolerances (it is not a reduced-precision path)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(64, 96, 80), (200, 300, 260), (130, 784, 256), (5, 7, 3)])
+def test_x3_half_steps(gpu_device, shape):
+    B, nv, nh = shape
+    W, b_h, b_v = synthetic_params(nv, nh, seed=800 + B)
+    W = (W * np.float32(3.7)).astype(np.float32)             # use all 24 significand bits
+    e = _engine(W, b_h, b_v, gpu_device)
+    rng = O.Rng(5, 3)
+    for v in (synthetic_binary(B, nv, seed=801 + B, p=0.3), synthetic_real(B, nv, seed=802 + B)):
+        vd = _dm(v, gpu_device)
+        assert e.v_pieces(vd) == (1 if np.array_equal(v, O.bf16_round(v)) else 3)
+        out = e.half_step_bf16("vh", vd, B, 0, 1, 5, 2, 3, pieces=3)
+        check_half_step(out, *O.sample_hidden(v, W, b_h, rng, 2))
+        out = e.half_step_bf16("vh", vd, B, 0, 0, 5, 0, 0, pieces=3)          # probabilities only
+        assert np.max(np.abs(out["prob"].to_numpy() - O.hidden_prob(v, W, b_h))) <= TOL
+    h = synthetic_binary(B, nh, seed=803 + B, p=0.5)
+    out = e.half_step_bf16("hv", _dm(h, gpu_device), B, 0, 1, 5, 3, 3, pieces=3)
+    check_half_step(out, *O.sample_visible(h, W, b_v, rng, 3))
+
+
+def test_x3_is_not_reduced_precision(gpu_device):
+    """Pre-activation error against float64: the x3 path is at least as accurate as the fp32 MFMA path
+    (pieces are exact and their products are exact in fp32; only the order of fp32 additions differs),
+    while the rounded-bf16 path is two orders of magnitude away."""
+    B, nv, nh = 512, 784, 1024
+    W, b_h, b_v = synthetic_params(nv, nh, seed=1)
+    e = _engine(W, b_h, b_v, gpu_device)
+    errs = {}
+    for name, v in (("binary", synthetic_binary(B, nv, seed=5)), ("real", synthetic_real(B, nv, seed=6))):
+        vd = _dm(v, gpu_device)
+        x64 = v.astype(np.float64) @ W.astype(np.float64) + b_h.astype(np.float64)
+        p64 = 1.0 / (1.0 + np.exp(-x64))
+        p32 = e.half_step("vh", vd, B, 0, 0, 0, 0, 0, 0, want_sample=False, want_prob=True)["prob"].to_numpy()
+        px3 = e.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=3)["prob"].to_numpy()
+        pbf = e.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=1)["prob"].to_numpy()
+        errs[name] = [float(np.max(np.abs(p - p64))) for p in (p32, px3, pbf)]
+        assert errs[name][1] <= max(2.0 * errs[name][0], 5e-7), errs
+        assert errs[name][1] <= 1e-6, errs
+    assert errs["real"][2] > 20 * errs["real"][1], errs       # the rounded path IS reduced precision
+    print("max |p - p_float64|  (fp32 MFMA, x3, rounded bf16):", errs)
+
+
+@pytest.mark.parametrize("cfg", [dict(B=64, nv=96, nh=80, k=1), dict(B=150, nv=200, nh=136, k=3),
+                                 dict(B=72, nv=128, nh=128, k=2, pcd=True), dict(B=256, nv=784, nh=256, k=1),
+                                 dict(B=133, nv=100, nh=70, k=1, real=True), dict(B=9, nv=5, nh=3, k=1)])
+def test_x3_cd_step_vs_oracle(gpu_device, cfg):
+    """CD-k / PCD on the x3 path against the fp32 oracle, fp32 tolerances."""
+    B, nv, nh, k = cfg["B"], cfg["nv"], cfg["nh"], cfg["k"]
+    W, b_h, b_v = synthetic_params(nv, nh, seed=900 + B)
+    v = synthetic_real(B, nv, seed=901 + B) if cfg.get("real") else synthetic_binary(B, nv, seed=901 + B, p=0.3)
+    chain0 = synthetic_binary(B, nv, seed=902 + B, p=0.5) if cfg.get("pcd") else None
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(v, gpu_device)
+    cd = _dm(chain0, gpu_device) if chain0 is not None else None
+    d1 = _gpu_cd_delta(e, vd, B, 0.05, 77, 9, k=k, v_chain=cd, compute="x3")
+    _, _, _, ch, (dW_ref, dbh_ref, dbv_ref) = O.cd_step_fused(W, b_h, b_v, v, 0.05, 77, 9, k=k, v_chain=chain0)
+    dW, dbh, dbv = _split(d1, nv, nh)
+    assert rel_err(dW, dW_ref) <= TOL
+    assert rel_err(dbh, dbh_ref) <= TOL
+    assert rel_err(dbv, dbv_ref) <= TOL
+    if cd is not None:
+        assert np.array_equal(cd.to_numpy(), ch["v_neg"])
+        cd = _dm(chain0, gpu_device)
+    d2 = _gpu_cd_delta(e, vd, B, 0.05, 77, 9, k=k, v_chain=cd, compute="x3")
+    assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32)), "same inputs, same counters -> same bits"
+    # in-place apply: fp32 master updated, the piece mirrors follow
+    e.cd_step(vd, B, 0, 0.05, 77, 9, k=k, v_chain=_dm(chain0, gpu_device) if chain0 is not None else None, compute="x3")
+    Wn, bhn, bvn = e.get_weights()
+    assert np.max(np.abs(Wn - (W + np.float32(0.05) * dW))) <= 1e-5
+    out = e.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=3)
+    assert np.max(np.abs(out["prob"].to_numpy() - O.hidden_prob(v, Wn, bhn))) <= TOL
+    # Gaussian visibles are outside the x3 path: the library says so instead of computing something else
+    from keras_unsupervised_amd._lib import KurbmError
+    with pytest.raises(KurbmError):
+        e.cd_step(vd, B, 0, 0.05, 77, 9, mode=O.MODE_VISIBLE_GAUSSIAN, compute="x3")
+
+
+def test_x3_full_size_properties(gpu_device):
+    """Config 2 on the x3 path: exact integer statistics, determinism, linearity in the batch, and
+    agreement with the fp32 MFMA path (identical draws; samples differ only in the rounding band)."""
+    B, nv, nh = 4096, 784, 1024
+    W, b_h, b_v = synthetic_params(nv, nh, seed=1)
+    v = synthetic_binary(B, nv, seed=1234)
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(v, gpu_device)
+    seed, step = 42, 17
+    d = _gpu_cd_delta(e, vd, B, 1e-3, seed, step, compute="x3")
+    d_again = _gpu_cd_delta(e, vd, B, 1e-3, seed, step, compute="x3")
+    assert np.array_equal(d.view(np.uint32), d_again.view(np.uint32))
+    dW, dbh, dbv = _split(d, nv, nh)
+    assert np.array_equal(dbv, np.round(dbv)) and np.abs(dbv).max() <= B       # counts of 0/1 states
+    # the fp32 MFMA path on the same counters
+    dW32, dbh32, dbv32 = _split(_gpu_cd_delta(e, vd, B, 1e-3, seed, step), nv, nh)
+    assert np.abs(dbv - dbv32).sum() <= 64                                     # a handful of borderline samples
+    assert np.linalg.norm(dW - dW32) <= 2e-3 * np.linalg.norm(dW32)
+    assert np.max(np.abs(1e-3 * dW - 1e-3 * dW32)) <= 1e-2                     # a flipped unit moves its row/column by <= lr
+    # stage-wise, teacher-forced on the fp32 path's samples: the statistics GEMM of the x3 step equals a
+    # float64 reference computed from ITS OWN chain states -- recover them through the half-step hook
+    o1 = e.half_step_bf16("vh", vd, B, 0, 1, seed, 0, step, pieces=3)
+    h_pos = o1["sample"].to_numpy()
+    o2 = e.half_step_bf16("hv", o1["sample"], B, 0, 1, seed, 1, step, pieces=3)
+    v_neg = o2["sample"].to_numpy()
+    o3 = e.half_step_bf16("vh", o2["sample"], B, 0, 0, seed, 0, step, pieces=3)
+    h_neg = o3["prob"].to_numpy()
+    pos = v.astype(np.float64).T @ h_pos.astype(np.float64)
+    neg = v_neg.astype(np.float64).T @ h_neg.astype(np.float64)
+    assert np.max(np.abs(dW - (pos - neg)) / (pos + neg + 1.0)) <= 4e-6
+    assert np.array_equal(dbv, v.sum(0) - v_neg.sum(0))
+    assert rel_err(dbh, h_pos.astype(np.float64).sum(0) - h_neg.astype(np.float64).sum(0)) <= TOL
+    # linearity: two half batches sum to the whole
+    da = _gpu_cd_delta(e, vd, B // 2, 1e-3, seed, step, compute="x3")
+    e.cd_step(vd, B // 2, B // 2, 1e-3, seed, step, apply=False, emit_delta=True, row0=B // 2, compute="x3")
+    torch.cuda.synchronize()
+    db = e.delta_buffer().cpu().numpy().copy()
+    assert np.max(np.abs(da + db - d)[: nv * nh] / (pos + neg + 1.0).ravel()) <= 4e-6
+
+
+def test_x3_rbm_fit_trajectory_golden(gpu_device, golden_dir):
+    """RBM(compute_dtype='x3').fit reproduces the fp32 oracle's golden trajectory."""
+    from keras_unsupervised_amd.ebm import MODE_VISIBLE_BERNOULLI, RBM
+    nv, nh = 64, 48
+    W, b_h, b_v = synthetic_params(nv, nh, seed=31)
+    V = synthetic_binary(150, nv, seed=32, p=0.3)
+    g = np.load(os.path.join(golden_dir, "fit_trajectory.npz"))
+    hps = {"batch_size": 64, "epochs": 1, "lr": 0.01}
+    for um in ("fused", "reference_sequential"):
+        r = RBM(hps, nh, mode=MODE_VISIBLE_BERNOULLI, seed=5, update_mode=um, weights=(W, b_h, b_v), compute_dtype="x3")
+        r.fit(V, verbose=0)
+        assert np.max(np.abs(r.rbm_weight - g["W_" + um])) <= TOL
+        assert np.max(np.abs(r.hidden_bias - g["bh_" + um])) <= TOL
+        assert np.max(np.abs(r.visible_bias - g["bv_" + um])) <= TOL

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""60 config-2 CD-1 steps on one compute path, for rocprofv3 --kernel-trace --stats:
+    rocprofv3 --kernel-trace --stats --output-format csv -d out -o x3 -- python3 tools/x3_profile_run.py x3"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from keras_unsupervised_amd.ebm.engine import DeviceMatrix, DeviceRBM  # noqa: E402
+
+compute = sys.argv[1] if len(sys.argv) > 1 else "x3"
+B, NV, NH = 4096, 784, 1024
+dev = torch.device("cuda", 0)
+g = np.random.default_rng(1)
+eng = DeviceRBM(g.uniform(-0.05, 0.05, (NV, NH)).astype(np.float32), np.zeros(NH, np.float32), np.zeros(NV, np.float32), dev)
+V = DeviceMatrix.from_host((g.random((B, NV)) < 0.19).astype(np.float32), dev)
+for i in range(60):
+    eng.cd_step(V, B, 0, 1e-3 / B, 42, i, compute=compute)
+torch.cuda.synchronize()
