@@ -540,20 +540,36 @@ struct WorkspaceB {
 
 struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_split, ld_slab; };
 
-static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg) {
+// pb: the statistics run on k_gemm_pb (x3): k-tile 64, one workgroup per CU, nseg segments walked
+// fastest, so a slice is a whole number of k positions
+static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, bool pb) {
     OuterPlanB pl;
     pl.gm = ceil_div(n_vis, 128);
     pl.gn = ceil_div(n_hid, 128);
-    pl.nkt = round_up(rows, 128) / 128;
+    pl.nkt = round_up(rows, 128) / (pb ? 64 : 128);
     pl.kt_total = nseg * pl.nkt;
-    int s = env_int("KURBM_BF16_SPLIT", (2 * ctx->ncu) / (pl.gm * pl.gn));
+    int s = env_int("KURBM_BF16_SPLIT", ((pb ? 1 : 2) * ctx->ncu) / (pl.gm * pl.gn));
     if (s < 1) s = 1;
-    if (s > pl.kt_total) s = pl.kt_total;
+    if (s > pl.nkt) s = pl.nkt;
     pl.nsplit_bound = s;
     pl.kt_per_split = ceil_div(pl.kt_total, s);
+    if (pb) pl.kt_per_split = round_up(pl.kt_per_split, nseg);
     pl.nsplit = ceil_div(pl.kt_total, pl.kt_per_split);
     pl.ld_slab = round_up(n_hid, 4);
     return pl;
+}
+
+// segment codes of k_gemm_pb: A piece ia against B pieces 0 .. npb-1
+static int pb_codes(int a_pieces, int b_pieces, unsigned set, unsigned long long* codes, int nseg) {
+    const bool full = env_int("KURBM_X3_FULL", 0) != 0;
+    for (int ia = 0; ia < a_pieces; ++ia) {
+        int npb = b_pieces;
+        if (a_pieces > 1 && b_pieces > 1 && !full) npb = b_pieces - ia;     // pairs with ia + ib <= 2
+        if (npb < 1) npb = 1;
+        *codes |= (unsigned long long)((unsigned)ia | ((unsigned)npb << 2) | (set << 4)) << (5 * nseg);
+        ++nseg;
+    }
+    return nseg;
 }
 
 static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_vis, int n_hid, int pieces, int v_pieces) {
@@ -567,7 +583,7 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.planeV = (size_t)w.Kb * w.Kv;
     w.planeVT = (size_t)n_vis * w.Kb;
     w.planeHT = (size_t)n_hid * w.Kb;
-    const OuterPlanB pl = plan_outer_bf16(ctx, rows, n_vis, n_hid, v_pieces + pieces);
+    const OuterPlanB pl = plan_outer_bf16(ctx, rows, n_vis, n_hid, pieces == 3 ? v_pieces + 1 : 2, pieces == 3);
     w.slab_stride = (size_t)n_vis * pl.ld_slab;
     char* b = static_cast<char*>(base);
     size_t off = 0;
@@ -625,6 +641,26 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
     g.A0 = A; g.lda = lda; g.a_plane0 = a_plane;
     g.B0 = vh ? m.Wtb : m.Wb; g.ldb = vh ? m.Kv : m.Kh; g.b_plane0 = vh ? m.planeWt : m.planeW;
     g.M = rows; g.N = vh ? p->n_hid : p->n_vis; g.K = vh ? m.Kv : m.Kh;
+    if (m.pieces == 3 && !env_int("KURBM_X3_SEGMENTS", 0)) {
+        // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip), 128 x 128 tiles
+        g.nseg = pb_codes(a_pieces, 3, 0u, &g.seg_codes, 0);
+        g.grid_m = ceil_div(rows, 128); g.grid_n = ceil_div(g.N, 128);
+        g.nkt = g.K / 64;
+        g.inv_nkt = inv_of(g.nkt);
+        g.kt_total = g.nseg * g.nkt; g.kt_per_split = g.kt_total; g.nsplit = 1;
+        g.bias = vh ? p->b_h : p->b_v;
+        g.act = act; g.noise = noise;
+        if (rng) g.rng = *rng;
+        g.out = o.out; g.ldo = o.ldo; g.ldo_cols = o.out ? o.ldo : g.N;
+        g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
+        g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
+        g.ref32 = o.ref32; g.ldref32 = o.ldref32; g.ref16 = o.ref16; g.ldref16 = o.ldref16;
+        g.colpart = o.colpart; g.ld_colpart = o.ld_colpart;
+        g.m_fastest = (g.grid_m < g.grid_n) ? 1 : 0;
+        if (o.grid_m_out) *o.grid_m_out = g.grid_m;
+        HIP_TRY(launch_gemm_pb(EPI_HALFSTEP, g, st));
+        return KURBM_OK;
+    }
     g.nseg = pair_codes(a_pieces, m.pieces, 0u, &g.seg_codes, 0);
     // tile choice: 128x128 when that already gives every CU two workgroups; the wave-specialised
     // 128x128 kernel (4 MFMA + 4 loader waves, one workgroup per CU) when there is about one tile per
@@ -779,7 +815,9 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
 
     // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
     // segments: (piece of v_pos) x h_pos, then v_neg x (piece of h_neg), negated
-    const OuterPlanB pl = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, v_pieces + pieces);
+    const bool pb = (pieces == 3) && !env_int("KURBM_X3_SEGMENTS", 0);
+    const OuterPlanB pl = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, pieces == 3 ? v_pieces + 1 : 2, pieces == 3);
+    int nslab_used = pl.nsplit;
     if (need_w) {
         GemmArgsB g;
         memset(&g, 0, sizeof g);
@@ -787,17 +825,30 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.A1 = w.v2bT; g.B1 = w.hnT; g.b_plane1 = w.planeHT;
         g.lda = w.Kb; g.ldb = w.Kb;
         g.M = p->n_vis; g.N = p->n_hid; g.K = w.Kb;
-        g.nseg = pair_codes(v_pieces, 1, 0u, &g.seg_codes, 0);
-        g.nseg = pair_codes(1, pieces, 1u, &g.seg_codes, g.nseg);
-        g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
-        g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
         g.grid_m = pl.gm; g.grid_n = pl.gn;
         g.slab = w.slab; g.slab_stride = w.slab_stride; g.ld_slab = pl.ld_slab;
-        HIP_TRY(launch_gemm_bf16(EPI_SLAB, g, st));
+        if (pb) {   // (piece of v_pos) x h_pos, then v_neg x (all pieces of h_neg), walked segment-fastest
+            g.nseg = pb_codes(v_pieces, 1, 0u, &g.seg_codes, 0);
+            g.nseg = pb_codes(1, 3, 1u, &g.seg_codes, g.nseg);
+            g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
+            g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
+            g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
+            HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
+        } else {
+            g.nseg = pair_codes(v_pieces, 1, 0u, &g.seg_codes, 0);
+            g.nseg = pair_codes(1, pieces, 1u, &g.seg_codes, g.nseg);
+            g.nkt = w.Kb / 128; g.inv_nkt = inv_of(g.nkt);
+            g.kt_total = g.nseg * g.nkt;
+            g.nsplit = pl.nsplit; g.kt_per_split = ceil_div(g.kt_total, g.nsplit);
+            g.nsplit = ceil_div(g.kt_total, g.kt_per_split);
+            nslab_used = g.nsplit;
+            HIP_TRY(launch_gemm_bf16(EPI_SLAB, g, st));
+        }
     }
     ReduceArgs a;
     memset(&a, 0, sizeof a);
-    a.slab = w.slab; a.slab_stride = w.slab_stride; a.nslab = pl.nsplit; a.ld_slab = pl.ld_slab;
+    a.slab = w.slab; a.slab_stride = w.slab_stride; a.ld_slab = pl.ld_slab;
+    a.nslab = nslab_used;
     a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw;
     a.nblk_w = need_w ? (int)(((long long)p->n_vis * (pl.ld_slab / 4) + 255) / 256) : 0;
     a.lr = o->lr;

@@ -116,6 +116,11 @@ struct GemmArgsB {
     size_t a_plane0, b_plane0, a_plane1, b_plane1;
     unsigned long long seg_codes;
     uint32_t inv_nkt;     // floor(2^32 / nkt) + 1: segment of k-tile t = umulhi(t, inv_nkt)
+    // k_gemm_pb (kurbm_x3.hip) reads the code as: bits 0-1 ia, bits 2-3 npb = number of B pieces
+    // (0 .. npb-1) multiplied with that A tile, bit 4 set; and may walk the segments FASTEST
+    // (t = k-tile * nseg + segment), so that every split-K slice gets the same mix of light and heavy tiles
+    int seg_fastest;
+    uint32_t inv_nseg;
     int lda, ldb;         // elements, multiples of 8
     int M, N, K;          // K per segment, multiple of 128
     int nseg, nkt, kt_total, kt_per_split, nsplit;
@@ -148,10 +153,14 @@ struct GemmArgsB {
     float* slab;
     size_t slab_stride;
     int ld_slab;
+    // diagnostic build only (KURBM_STAMPS): 8 x u64 per workgroup (k_gemm_pb)
+    unsigned long long* stamps;
 };
 
+unsigned long long* get_stamp_buffer();
 void tile_shape(int cfg, int* bm, int* bn);
 hipError_t launch_gemm_bf16(int epi, const GemmArgsB& g, hipStream_t st);
+hipError_t launch_gemm_pb(int epi, const GemmArgsB& g, hipStream_t st);
 // pieces = 1: round to nearest bf16; 3: exact split x = hi + mid + lo, piece j at out + j * out_plane
 hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
                               uint16_t* outT, int ldoT, int outT_rows, int pieces, size_t out_plane, size_t outT_plane,

@@ -766,6 +766,7 @@ void tile_shape(int cfg, int* bm, int* bn) {
 static unsigned long long* g_stamp_buffer = nullptr;
 static int g_dbg_off = 0;
 void set_stamp_buffer(unsigned long long* p) { g_stamp_buffer = p; }
+unsigned long long* get_stamp_buffer() { return g_stamp_buffer; }
 void set_debug_off(int mask) { g_dbg_off = mask; }
 
 hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g_in, hipStream_t st) {

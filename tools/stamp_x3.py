@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Phase lengths of the x3 GEMM launches of a config-2 CD-1 step (diagnostic build only):
+
+    make -C keras_unsupervised_amd/csrc libkurbm_stamps.so
+    KURBM_LIB=keras_unsupervised_amd/csrc/libkurbm_stamps.so python tools/stamp_x3.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+assert "stamps" in os.environ.get("KURBM_LIB", ""), "set KURBM_LIB to libkurbm_stamps.so"
+from keras_unsupervised_amd.ebm.engine import DeviceMatrix, DeviceRBM  # noqa: E402
+
+B, NV, NH = 4096, 784, 1024
+dev = torch.device("cuda", 0)
+g = np.random.default_rng(1)
+eng = DeviceRBM(g.uniform(-0.05, 0.05, (NV, NH)).astype(np.float32), np.zeros(NH, np.float32), np.zeros(NV, np.float32), dev)
+V = DeviceMatrix.from_host((g.random((B, NV)) < 0.19).astype(np.float32), dev)
+lib = eng.lib
+lib.kurbm_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+lib.kurbm_debug_set_stamp_buffer.restype = None
+buf = torch.zeros(8 * 4096, dtype=torch.int64, device=dev)
+NAMES = ["start skew", "prologue", "k loop", "elementwise", "flush", "tail"]
+
+
+def report(name, s):
+    s = s[s[:, 0] > 0]
+    t0 = s[:, 0].min()
+    d = [np.median(s[:, 0] - t0)]
+    for q in range(1, 6):
+        a, b = s[:, q - 1], s[:, q]
+        ok = (a > 0) & (b > 0)
+        d.append(np.median((b - a)[ok]) if ok.any() else 0.0)
+    end = s[:, 5].max() - t0
+    print("%-10s wgs %4d  whole launch %7.0f ticks | " % (name, len(s), end) + "  ".join("%s %6.0f" % (n, x) for n, x in zip(NAMES, d)))
+
+
+step = lambda: eng.cd_step(V, B, 0, 1e-3 / B, 42, 0, compute="x3")
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+buf.zero_()
+lib.kurbm_debug_set_stamp_buffer(buf.data_ptr())
+step()
+torch.cuda.synchronize()
+lib.kurbm_debug_set_stamp_buffer(None)
+s = buf.cpu().numpy().astype(np.float64).reshape(8, 512, 8)
+for n, name in enumerate(("vh sample", "hv sample", "vh prob", "statistics")):
+    report(name, s[n])

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from keras_unsupervised_amd.ebm.engine import DeviceMatrix, DeviceRBM  # noqa: E402
 
 compute = sys.argv[1] if len(sys.argv) > 1 else "x3"
-B, NV, NH = 4096, 784, 1024
+B, NV, NH = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (4096, 784, 1024)
 dev = torch.device("cuda", 0)
 g = np.random.default_rng(1)
 eng = DeviceRBM(g.uniform(-0.05, 0.05, (NV, NH)).astype(np.float32), np.zeros(NH, np.float32), np.zeros(NV, np.float32), dev)
