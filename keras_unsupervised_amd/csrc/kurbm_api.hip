@@ -513,15 +513,21 @@ void kurbm_debug_set_off(int mask) { set_debug_off(mask); }
 //   pieces = 3  "x3":   every fp32 operand carried EXACTLY as three bf16 pieces (hi + mid + lo), one
 //                       k-segment of the NT GEMM per pair of pieces; 0/1 samples are a single piece
 // ======================================================================================
-struct Mirror { uint16_t *Wb, *Wtb; int Kh, Kv, pieces; size_t planeW, planeWt, bytes; };
+// Leading dimensions of every bf16 plane are the k extent plus one 128-byte line: a row stride that is a
+// multiple of 2 KiB (k = 1024, 4096 ...) would send a whole column of a tile to ONE L2 channel.
+static inline int ld_pad(int k) { return k + env_int("KURBM_LDPAD", 64); }
+
+struct Mirror { uint16_t *Wb, *Wtb; int Kh, Kv, ldW, ldWt, pieces; size_t planeW, planeWt, bytes; };
 
 static Mirror carve_mirror(void* base, int n_vis, int n_hid, int pieces) {
     Mirror m;
     m.pieces = pieces;
     m.Kh = round_up(n_hid, 128);   // k extent of W  [n_vis][Kh]   (B operand of h->v)
     m.Kv = round_up(n_vis, 128);   // k extent of Wt [n_hid][Kv]   (B operand of v->h)
-    m.planeW = (size_t)n_vis * m.Kh;
-    m.planeWt = (size_t)n_hid * m.Kv;
+    m.ldW = ld_pad(m.Kh);
+    m.ldWt = ld_pad(m.Kv);
+    m.planeW = (size_t)n_vis * m.ldW;
+    m.planeWt = (size_t)n_hid * m.ldWt;
     char* b = static_cast<char*>(base);
     size_t off = 0;
     m.Wb = reinterpret_cast<uint16_t*>(b + off);  off = align_up(off + pieces * m.planeW * 2);
@@ -533,7 +539,7 @@ static Mirror carve_mirror(void* base, int n_vis, int n_hid, int pieces) {
 struct WorkspaceB {
     uint16_t *vb, *vbT, *hb, *hbT, *v2b, *v2bT, *h2b, *hnT, *cb;
     float *part_h, *part_v, *slab, *tmp32;
-    int Kv, Kh, Kb, ldh32, ldv32, max_row_tiles;
+    int Kv, Kh, Kb, Lv, Lh, Lb, ldh32, ldv32, max_row_tiles;   // K*: k extents; L*: leading dimensions of the bf16 planes
     size_t planeV, planeVT, planeHT;   // distance between the pieces of v_pos (both images) and of h_neg^T
     size_t slab_stride, bytes;
 };
@@ -577,12 +583,13 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.Kv = round_up(n_vis, 128);
     w.Kh = round_up(n_hid, 128);
     w.Kb = round_up(rows, 128);
+    w.Lv = ld_pad(w.Kv); w.Lh = ld_pad(w.Kh); w.Lb = ld_pad(w.Kb);
     w.ldh32 = round_up(n_hid, 4);
     w.ldv32 = round_up(n_vis, 4);
     w.max_row_tiles = ceil_div(rows, 128);
-    w.planeV = (size_t)w.Kb * w.Kv;
-    w.planeVT = (size_t)n_vis * w.Kb;
-    w.planeHT = (size_t)n_hid * w.Kb;
+    w.planeV = (size_t)w.Kb * w.Lv;
+    w.planeVT = (size_t)n_vis * w.Lb;
+    w.planeHT = (size_t)n_hid * w.Lb;
     const OuterPlanB pl = plan_outer_bf16(ctx, rows, n_vis, n_hid, pieces == 3 ? v_pieces + 1 : 2, pieces == 3);
     w.slab_stride = (size_t)n_vis * pl.ld_slab;
     char* b = static_cast<char*>(base);
@@ -590,13 +597,15 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     auto take16 = [&](size_t n) { uint16_t* p = reinterpret_cast<uint16_t*>(b + off); off = align_up(off + n * 2); return p; };
     auto take32 = [&](size_t n) { float* p = reinterpret_cast<float*>(b + off); off = align_up(off + n * 4); return p; };
     w.vb = take16(v_pieces * w.planeV);    w.vbT = take16(v_pieces * w.planeVT);     // v_pos, both orientations
-    w.hb = take16((size_t)w.Kb * w.Kh);    w.hbT = take16((size_t)n_hid * w.Kb);     // h_pos
-    w.v2b = take16((size_t)w.Kb * w.Kv);   w.v2bT = take16((size_t)n_vis * w.Kb);    // v_t / v_neg
-    w.h2b = take16((size_t)w.Kb * w.Kh);                                             // h_t (k > 1, chain start)
+    w.hb = take16((size_t)w.Kb * w.Lh);    w.hbT = take16((size_t)n_hid * w.Lb);     // h_pos
+    w.v2b = take16((size_t)w.Kb * w.Lv);   w.v2bT = take16((size_t)n_vis * w.Lb);    // v_t / v_neg
+    w.h2b = take16((size_t)w.Kb * w.Lh);                                             // h_t (k > 1, chain start)
     w.hnT = take16(pieces * w.planeHT);                                              // h_neg probabilities, transposed
     w.cb = take16(v_pieces * w.planeV);                                              // persistent chain as bf16
-    w.part_h = take32((size_t)w.max_row_tiles * w.ldh32);
-    w.part_v = take32((size_t)w.max_row_tiles * w.ldv32);
+    // bias partials.  bf16: one row per row tile.  x3: hidden = rows of +sum(h_pos) then rows of -sum(h_neg);
+    // visible = one row per 32-row band of v_pos (conversion kernel) then rows of -sum(v_neg)
+    w.part_h = take32((size_t)2 * w.max_row_tiles * w.ldh32);
+    w.part_v = take32((size_t)(ceil_div(rows, 32) + w.max_row_tiles) * w.ldv32);
     w.slab = take32(w.slab_stride * pl.nsplit_bound);
     w.tmp32 = take32((size_t)rows * (w.ldh32 > w.ldv32 ? w.ldh32 : w.ldv32));       // fp32 plane for the test hook
     w.bytes = off;
@@ -628,6 +637,7 @@ struct HalfOutB {
     const float* ref32 = nullptr; int ldref32 = 0;        // column partials of (ref - value)
     const uint16_t* ref16 = nullptr; int ldref16 = 0;
     float* colpart = nullptr; int ld_colpart = 0;
+    float colsign = 1.f;                                  // x3: colpart = colsign * column sums of the value plane
     int* grid_m_out = nullptr;
 };
 
@@ -639,7 +649,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
     memset(&g, 0, sizeof g);
     const bool vh = (layout == LAYOUT_VH);
     g.A0 = A; g.lda = lda; g.a_plane0 = a_plane;
-    g.B0 = vh ? m.Wtb : m.Wb; g.ldb = vh ? m.Kv : m.Kh; g.b_plane0 = vh ? m.planeWt : m.planeW;
+    g.B0 = vh ? m.Wtb : m.Wb; g.ldb = vh ? m.ldWt : m.ldW; g.b_plane0 = vh ? m.planeWt : m.planeW;
     g.M = rows; g.N = vh ? p->n_hid : p->n_vis; g.K = vh ? m.Kv : m.Kh;
     if (m.pieces == 3 && !env_int("KURBM_X3_SEGMENTS", 0)) {
         // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip), 128 x 128 tiles
@@ -655,8 +665,10 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
         g.ref32 = o.ref32; g.ldref32 = o.ldref32; g.ref16 = o.ref16; g.ldref16 = o.ldref16;
-        g.colpart = o.colpart; g.ld_colpart = o.ld_colpart;
-        g.m_fastest = (g.grid_m < g.grid_n) ? 1 : 0;
+        g.colpart = o.colpart; g.ld_colpart = o.ld_colpart; g.colsign = o.colsign;
+        // row tiles fastest: an XCD's run of workgroups then shares ONE column tile, whose weight pieces
+        // (the operand loaded straight into registers, one tile ahead) stay in that XCD's L2
+        g.m_fastest = env_int("KURBM_X3_MFAST", 1);
         if (o.grid_m_out) *o.grid_m_out = g.grid_m;
         HIP_TRY(launch_gemm_pb(EPI_HALFSTEP, g, st));
         return KURBM_OK;
@@ -692,8 +704,8 @@ static int mirror_refresh_any(kurbm_ctx* ctx, int pieces, const kurbm_params* p,
     if (!mirror || !aligned16(mirror)) return fail(KURBM_ERR_ARG, "mirror is null or misaligned");
     const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, pieces);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
-    HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.Kh, p->n_vis, m.Wtb, m.Kv, p->n_hid, pieces,
-                               m.planeW, m.planeWt, static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, pieces,
+                               m.planeW, m.planeWt, nullptr, 0, static_cast<hipStream_t>(stream)));
     return KURBM_OK;
 }
 
@@ -715,12 +727,12 @@ static int half_step_any(kurbm_ctx* ctx, int pieces, int in_pieces, const kurbm_
     const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, pieces);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small");
     // the input plane is staged in the larger of the two row-major buffers' shapes: use a private carve
-    const int Kp = round_up(K, 128), Kb = round_up(rows, 128);
+    const int Kp = ld_pad(round_up(K, 128)), Kb = round_up(rows, 128);   // Kp: leading dimension of the staged input
     const size_t plane = (size_t)Kb * Kp;
     const size_t need = align_up(in_pieces * plane * 2);
     if (need > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     uint16_t* Ab = static_cast<uint16_t*>(workspace);
-    HIP_TRY(launch_f32_to_bf16(in, rows, K, ld_in, Ab, Kp, Kb, nullptr, 0, 0, in_pieces, plane, 0, st));
+    HIP_TRY(launch_f32_to_bf16(in, rows, K, ld_in, Ab, Kp, Kb, nullptr, 0, 0, in_pieces, plane, 0, nullptr, 0, st));
     RngArgs r;
     if (rng) r = make_rng(rng->seed, rng->row0, rng->stream_id, rng->step);
     HalfOutB o;
@@ -762,22 +774,26 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     int e;
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
-    HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Kv, w.Kb, w.vbT, w.Kb, p->n_vis, v_pieces, w.planeV,
-                               w.planeVT, st));
+    // (x3: plus the column sums of v_pos per 32-row band, the positive half of the visible-bias statistics)
+    const bool pb = (pieces == 3) && !env_int("KURBM_X3_SEGMENTS", 0);
+    const int gp_v = pb ? ceil_div(rows, 32) : 0;
+    HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Lv, w.Kb, w.vbT, w.Lb, p->n_vis, v_pieces, w.planeV,
+                               w.planeVT, pb ? w.part_v : nullptr, w.ldv32, st));
     // h_pos ~ p(h | v_pos)                                          rbm.py:120
     RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
     {
         HalfOutB ho;
-        ho.out = w.hb; ho.ldo = w.Kh; ho.outT = w.hbT; ho.ldoT = w.Kb;
-        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Kv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
+        ho.out = w.hb; ho.ldo = w.Lh; ho.outT = w.hbT; ho.ldoT = w.Lb;
+        if (pb) { ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.colsign = 1.f; }
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
     }
     const uint16_t* h_cur = w.hb;
     if (o->v_chain) {   // persistent chain: negative phase starts from the stored fantasy particles
-        HIP_TRY(launch_f32_to_bf16(o->v_chain, rows, p->n_vis, ldv, w.cb, w.Kv, w.Kb, nullptr, 0, 0, v_pieces, w.planeV, 0, st));
+        HIP_TRY(launch_f32_to_bf16(o->v_chain, rows, p->n_vis, ldv, w.cb, w.Lv, w.Kb, nullptr, 0, 0, v_pieces, w.planeV, 0, nullptr, 0, st));
         r = make_rng(o->seed, o->row0, base + 32u, o->step);
         HalfOutB ho;
-        ho.out = w.h2b; ho.ldo = w.Kh;
-        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.cb, w.Kv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
+        ho.out = w.h2b; ho.ldo = w.Lh;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.cb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
         h_cur = w.h2b;
     }
     int gm_v = 0, gm_h = 0;
@@ -786,36 +802,40 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         r = make_rng(o->seed, o->row0, base + 2u * t - 1u, o->step);      // v_t ~ p(v | h_{t-1})   rbm.py:121-123
         {
             HalfOutB ho;
-            ho.out = w.v2b; ho.ldo = w.Kv;
+            ho.out = w.v2b; ho.ldo = w.Lv;
             if (last) {
-                ho.outT = w.v2bT; ho.ldoT = w.Kb;
+                ho.outT = w.v2bT; ho.ldoT = w.Lb;
                 ho.out_f32 = o->v_chain; ho.ldo32 = ldv;
                 ho.ref32 = v_batch; ho.ldref32 = ldv;
                 ho.grid_m_out = &gm_v;
             }
             ho.colpart = w.part_v; ho.ld_colpart = w.ldv32;
-            if ((e = half_step_b(ctx, LAYOUT_HV, p, m, h_cur, w.Kh, 1, 0, rows, act_v, noise_v, &r, ho, st))) return e;
+            if (pb) {   // -sum(v_neg) below the bands of +sum(v_pos); nothing for the inner steps of CD-k
+                ho.colpart = last ? w.part_v + (size_t)gp_v * w.ldv32 : nullptr;
+                ho.colsign = -1.f;
+            }
+            if ((e = half_step_b(ctx, LAYOUT_HV, p, m, h_cur, w.Lh, 1, 0, rows, act_v, noise_v, &r, ho, st))) return e;
         }
         if (!last) {
             r = make_rng(o->seed, o->row0, base + 2u * t, o->step);
             HalfOutB ho;
-            ho.out = w.h2b; ho.ldo = w.Kh;
-            if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Kv, 1, 0, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
+            ho.out = w.h2b; ho.ldo = w.Lh;
+            if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, 1, 0, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
             h_cur = w.h2b;
         }
     }
     // h_neg = sigmoid(v_neg.W + b_h), probabilities (rbm.py:124): only its transposed image is needed
     {
         HalfOutB ho;
-        ho.outT = w.hnT; ho.ldoT = w.Kb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT;
-        ho.ref16 = w.hb; ho.ldref16 = w.Kh;
+        ho.outT = w.hnT; ho.ldoT = w.Lb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT;
+        ho.ref16 = w.hb; ho.ldref16 = w.Lh;
         ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.grid_m_out = &gm_h;
-        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Kv, 1, 0, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st))) return e;
+        if (pb) { ho.colpart = w.part_h + (size_t)ceil_div(rows, 128) * w.ldh32; ho.colsign = -1.f; }
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, 1, 0, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st))) return e;
     }
 
     // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
     // segments: (piece of v_pos) x h_pos, then v_neg x (piece of h_neg), negated
-    const bool pb = (pieces == 3) && !env_int("KURBM_X3_SEGMENTS", 0);
     const OuterPlanB pl = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, pieces == 3 ? v_pieces + 1 : 2, pieces == 3);
     int nslab_used = pl.nsplit;
     if (need_w) {
@@ -823,7 +843,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         memset(&g, 0, sizeof g);
         g.A0 = w.vbT; g.a_plane0 = w.planeVT; g.B0 = w.hbT;
         g.A1 = w.v2bT; g.B1 = w.hnT; g.b_plane1 = w.planeHT;
-        g.lda = w.Kb; g.ldb = w.Kb;
+        g.lda = w.Lb; g.ldb = w.Lb;
         g.M = p->n_vis; g.N = p->n_hid; g.K = w.Kb;
         g.grid_m = pl.gm; g.grid_n = pl.gn;
         g.slab = w.slab; g.slab_stride = w.slab_stride; g.ld_slab = pl.ld_slab;
@@ -855,16 +875,16 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     const bool ap = o->apply != 0;
     a.W = (ap && (which & 1)) ? p->W : nullptr;
     a.delta_w = o->delta_out;
-    a.part_h = w.part_h; a.nrow_tiles_h = gm_h; a.ld_part_h = w.ldh32;
+    a.part_h = w.part_h; a.nrow_tiles_h = pb ? 2 * gm_h : gm_h; a.ld_part_h = w.ldh32;
     a.b_h = (ap && (which & 2)) ? p->b_h : nullptr;
     a.delta_bh = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid : nullptr;
-    a.part_v = w.part_v; a.nrow_tiles_v = gm_v; a.ld_part_v = w.ldv32;
+    a.part_v = w.part_v; a.nrow_tiles_v = pb ? gp_v + gm_v : gm_v; a.ld_part_v = w.ldv32;
     a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
     a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
     HIP_TRY(launch_reduce_apply(a, st));
     if (a.W)   // the fp32 master moved: re-derive both mirrors
-        HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.Kh, p->n_vis, m.Wtb, m.Kv, p->n_hid, pieces,
-                                   m.planeW, m.planeWt, st));
+        HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, pieces,
+                                   m.planeW, m.planeWt, nullptr, 0, st));
     return KURBM_OK;
 }
 

@@ -40,7 +40,8 @@ constexpr int NTH = 256;
 __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ in, int rows, int cols, int ld_in,
                                                      uint16_t* __restrict__ out, int ldo, int out_rows,
                                                      uint16_t* __restrict__ outT, int ldoT, int outT_rows,
-                                                     int pieces, size_t out_plane, size_t outT_plane) {
+                                                     int pieces, size_t out_plane, size_t outT_plane,
+                                                     float* __restrict__ colpart, int ld_colpart) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -58,8 +59,15 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
             }
         }
     }
-    if (!outT) return;
+    if (!outT && !colpart) return;
     __syncthreads();
+    if (colpart && ty == 0 && r0 < rows && c0 + tx < cols) {   // out-of-range elements were staged as zeros
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += tile[i][tx];
+        colpart[(size_t)blockIdx.y * ld_colpart + c0 + tx] = t;
+    }
+    if (!outT) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = c0 + ty + 8 * j, r = r0 + tx;   // outT[c][r]
@@ -509,14 +517,14 @@ __global__ __launch_bounds__(WS ? 2 * NTH : NTH) void k_gemm_bf16(GemmArgsB g) {
 // ------------------------------------------------------------------------------------
 hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
                               uint16_t* outT, int ldoT, int outT_rows, int pieces, size_t out_plane, size_t outT_plane,
-                              hipStream_t st) {
+                              float* colpart, int ld_colpart, hipStream_t st) {
     // cover the padded extents of whichever mirrors are requested
     int r_ext = rows, c_ext = cols;
     if (out) { if (out_rows > r_ext) r_ext = out_rows; if (ldo > c_ext) c_ext = ldo; }
     if (outT) { if (ldoT > r_ext) r_ext = ldoT; if (outT_rows > c_ext) c_ext = outT_rows; }
     dim3 grid((c_ext + 31) / 32, (r_ext + 31) / 32);
     hipLaunchKernelGGL(k_f32_to_bf16, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
-                       outT_rows, pieces, out_plane, outT_plane);
+                       outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart);
     return hipGetLastError();
 }
 

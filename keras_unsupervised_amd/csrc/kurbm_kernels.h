@@ -121,6 +121,12 @@ struct GemmArgsB {
     // (t = k-tile * nseg + segment), so that every split-K slice gets the same mix of light and heavy tiles
     int seg_fastest;
     uint32_t inv_nseg;
+    int rotate;           // k_gemm_pb: stagger the k walk of neighbouring workgroups (L2 reuse), see the kernel
+    // filled by launch_gemm_pb: one buffer descriptor per operand (base = the lower of the two sets'
+    // pointers) and each set's byte offset from it, so that a tile is a scalar offset, never a pointer
+    const uint16_t* baseA;
+    const uint16_t* baseB;
+    uint32_t offA0, offA1, offB0, offB1;
     int lda, ldb;         // elements, multiples of 8
     int M, N, K;          // K per segment, multiple of 128
     int nseg, nkt, kt_total, kt_per_split, nsplit;
@@ -149,6 +155,7 @@ struct GemmArgsB {
     int ldref16;
     float* colpart;
     int ld_colpart;
+    float colsign;        // k_gemm_pb: colpart[bm][col] = colsign * (column sum of the value plane over the tile's rows)
     // slab epilogue
     float* slab;
     size_t slab_stride;
@@ -162,9 +169,10 @@ void tile_shape(int cfg, int* bm, int* bn);
 hipError_t launch_gemm_bf16(int epi, const GemmArgsB& g, hipStream_t st);
 hipError_t launch_gemm_pb(int epi, const GemmArgsB& g, hipStream_t st);
 // pieces = 1: round to nearest bf16; 3: exact split x = hi + mid + lo, piece j at out + j * out_plane
+// colpart (nullable): [ceil(rows / 32)][ld_colpart] column sums of each 32-row band of `in`
 hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
                               uint16_t* outT, int ldoT, int outT_rows, int pieces, size_t out_plane, size_t outT_plane,
-                              hipStream_t st);
+                              float* colpart, int ld_colpart, hipStream_t st);
 hipError_t launch_bf16_exact_check(const float* in, int rows, int cols, int ld_in, int* flag, hipStream_t st);
 hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g, hipStream_t st);
 hipError_t launch_philox_uniform(float* out, int rows, int cols, int ld, const RngArgs& rng, hipStream_t st);
