@@ -604,8 +604,9 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.cb = take16(v_pieces * w.planeV);                                              // persistent chain as bf16
     // bias partials.  bf16: one row per row tile.  x3: hidden = rows of +sum(h_pos) then rows of -sum(h_neg);
     // visible = one row per 32-row band of v_pos (conversion kernel) then rows of -sum(v_neg)
-    w.part_h = take32((size_t)2 * w.max_row_tiles * w.ldh32);
-    w.part_v = take32((size_t)(ceil_div(rows, 32) + w.max_row_tiles) * w.ldv32);
+    // (k_gemm_pb writes one row per 64-row half of a 128-row tile: two rows per tile)
+    w.part_h = take32((size_t)4 * w.max_row_tiles * w.ldh32);
+    w.part_v = take32((size_t)(ceil_div(rows, 32) + 2 * w.max_row_tiles) * w.ldv32);
     w.slab = take32(w.slab_stride * pl.nsplit_bound);
     w.tmp32 = take32((size_t)rows * (w.ldh32 > w.ldv32 ? w.ldh32 : w.ldv32));       // fp32 plane for the test hook
     w.bytes = off;
@@ -830,7 +831,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         ho.outT = w.hnT; ho.ldoT = w.Lb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT;
         ho.ref16 = w.hb; ho.ldref16 = w.Lh;
         ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.grid_m_out = &gm_h;
-        if (pb) { ho.colpart = w.part_h + (size_t)ceil_div(rows, 128) * w.ldh32; ho.colsign = -1.f; }
+        if (pb) { ho.colpart = w.part_h + (size_t)2 * ceil_div(rows, 128) * w.ldh32; ho.colsign = -1.f; }
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, 1, 0, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st))) return e;
     }
 
@@ -875,10 +876,10 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     const bool ap = o->apply != 0;
     a.W = (ap && (which & 1)) ? p->W : nullptr;
     a.delta_w = o->delta_out;
-    a.part_h = w.part_h; a.nrow_tiles_h = pb ? 2 * gm_h : gm_h; a.ld_part_h = w.ldh32;
+    a.part_h = w.part_h; a.nrow_tiles_h = pb ? 4 * gm_h : gm_h; a.ld_part_h = w.ldh32;
     a.b_h = (ap && (which & 2)) ? p->b_h : nullptr;
     a.delta_bh = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid : nullptr;
-    a.part_v = w.part_v; a.nrow_tiles_v = pb ? gp_v + gm_v : gm_v; a.ld_part_v = w.ldv32;
+    a.part_v = w.part_v; a.nrow_tiles_v = pb ? gp_v + 2 * gm_v : gm_v; a.ld_part_v = w.ldv32;
     a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
     a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
     HIP_TRY(launch_reduce_apply(a, st));

@@ -121,7 +121,7 @@ struct GemmArgsB {
     // (t = k-tile * nseg + segment), so that every split-K slice gets the same mix of light and heavy tiles
     int seg_fastest;
     uint32_t inv_nseg;
-    int rotate;           // k_gemm_pb: stagger the k walk of neighbouring workgroups (L2 reuse), see the kernel
+    int side;             // k_gemm_pb: some test plane (prob_f32 / out_u) is requested
     // filled by launch_gemm_pb: one buffer descriptor per operand (base = the lower of the two sets'
     // pointers) and each set's byte offset from it, so that a tile is a scalar offset, never a pointer
     const uint16_t* baseA;

@@ -4,26 +4,29 @@
 // hi + mid + lo with three bf16 pieces (kurbm_device.h: bf16_piece_bits).  In a CD step one operand of
 // every product is a 0/1 sample (one exact piece) and the other is real-valued (W, or the h_neg
 // probabilities): A . B = A . B_hi + A . B_mid + A . B_lo, three bf16 MFMAs into the SAME fp32
-// accumulators.
-//
-// Layout of the work (what a 128 x 128 bf16 tile needs to stay off the LDS and L1 limits of a CU):
-//   * A (the 0/1 side, [M][K] bf16): one 128 x 64 tile per k-step through LDS, shared by all 8 waves,
-//     staged global -> registers -> LDS two tiles ahead, double-buffered, one barrier per tile.
-//   * B (the pieces, [N][K] bf16 each): NOT through LDS.  Wave w owns columns 16w .. 16w+15 of the tile;
-//     the MFMA B fragment of a lane (column l15, k chunk `slot`) is 16 contiguous bytes of row l15 of the
-//     mirror, so each wave loads its own fragments straight into registers one tile ahead.  No other
-//     wave needs them: no redundancy, and the LDS carries a quarter of the bytes it would otherwise.
-//   * per k-step a wave reads its 8 A fragments once and multiplies them with the fragments of every
-//     piece: 24 MFMAs per 8 ds_read_b128.
+// accumulators.  So this kernel's k-tile holds ONE tile of A and up to PB = 3 tiles of B (the pieces of
+// the same rows), LDS-staged: per k-step a wave reads its A fragments once and multiplies them with the
+// fragments of every piece.  Against running the three products as consecutive k ranges
+// (kurbm_bf16.hip) that is a third fewer bytes from L2 and through LDS per MFMA.
 //
 // Segments (GemmArgsB::seg_codes): segment s multiplies piece `ia` of A (set 0 or 1) with pieces
 // 0 .. npb-1 of B of the same set; set 1 enters negated (negative phase of the statistics).  A
 // real-valued A (grey-level data) is three segments (ia = 0, 1, 2 with npb = 3, 2, 1).
 //
-// Epilogue of a half step, all from registers: bias + activation + Philox draw; column sums of the
-// value plane (bias statistics; the wave owns whole columns of the tile); the transposed bf16 plane(s)
-// as 8-byte stores (a lane holds 4 consecutive rows of its column); only the row-major bf16 plane
-// takes a trip through LDS (bf16 patch of the whole tile, then 16-byte coalesced rows).
+// Tile 128 x 128, k-tile 64, 8 waves (2 x 4, 64 x 32 outputs each), two per SIMD: while one waits for
+// LDS or the barrier the other issues MFMAs.  Staging global -> registers -> LDS with buffer loads (a
+// constant per-lane offset + one scalar offset per tile: no vector address arithmetic in the loop),
+// double-buffered in LDS, fetched two tiles ahead, one barrier per tile.
+//
+// Epilogue of a half step, from registers: bias + activation + Philox draw; column sums of the value
+// plane (bias statistics); the transposed bf16 plane(s) as 8-byte stores (a lane holds 4 consecutive
+// rows of its column); only the row-major bf16 plane takes a trip through LDS (bf16 patch of the whole
+// tile, then 16-byte coalesced rows).
+//
+// Measured limits (MI355X, config 2): the k loop runs at ~45 % of the bf16 MFMA
+// rate; L2 hit rate 70 % (half steps) / 20 % (statistics): the operands stream from the Infinity Cache.
+// A variant with the pieces loaded straight into registers (no LDS for B) was 15 % slower, padding the
+// leading dimensions and staggering the k walk of neighbouring workgroups changed nothing.
 //
 // Reference op sequences: ku/ebm/rbm.py:46-47 (v->h), :52-53 / :121-123 (h->v), :124 (h_neg), :125-134
 // (statistics); the split is an implementation choice of this build.
@@ -56,41 +59,39 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define KURBM_STAMP(var) do { } while (0)
 #endif
 
-template <int NWAVES, int BKB, int PB, int EPI, int NOISE>
-__global__ __launch_bounds__(64 * NWAVES) void k_gemm_pb(GemmArgsB g) {
-    constexpr int BM = 128, BN = 16 * NWAVES;
-    constexpr int NT = 64 * NWAVES;
-    constexpr int ROWB = 2 * BKB + 16;    // LDS row of the A tile: k-tile + 16 B pad -> conflict-free ds_read_b128
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int PB, int EPI, int NOISE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_pb(GemmArgsB g) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int ROWB = 2 * BKB + 16;    // LDS row: k-tile + 16 B pad -> conflict-free ds_read_b128
     constexpr int CPR = BKB / 8;          // 16-B chunks per row
     constexpr int KS = BKB / 32;          // MFMA k-steps per tile
-    static_assert(KS == 2, "A fragment buffers alternate with the k-step");
-    constexpr int TM = BM / 16;
-    constexpr int A_BYTES = BM * ROWB;
-    constexpr int NA = BM * CPR / NT;     // 16-B chunks of the A tile per lane
-    static_assert((BM * CPR) % NT == 0, "whole chunks per lane");
+    static_assert(KS == 2, "fragment buffers alternate with the k-step");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int A_BYTES = BM * ROWB, B1_BYTES = BN * ROWB, B_BYTES = PB * B1_BYTES;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = BM * CPR / NT, NB1 = BN * CPR / NT;   // 16-B chunks per lane: A tile, ONE piece of B
+    static_assert((BM * CPR) % NT == 0 && (BN * CPR) % NT == 0, "whole chunks per lane");
     constexpr int PROW16 = 2 * BN + 16;   // bf16 patch row (bytes)
     constexpr int PROW32 = 4 * BN + 16;   // fp32 patch row (bytes)
     constexpr int PATCH_BYTES = BM * (EPI == EPI_SLAB ? PROW32 : PROW16);
-    constexpr int SMEM_BYTES = (2 * A_BYTES > PATCH_BYTES) ? 2 * A_BYTES : PATCH_BYTES;
+    constexpr int SMEM_BYTES = (2 * STAGE > PATCH_BYTES) ? 2 * STAGE : PATCH_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l15 = lane & 15, slot = lane >> 4;
 #ifdef KURBM_STAMPS
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long tu[7] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tv[3] = {0, 0, 0};   // inside micro-step 0: issue the loads, park, issue the fragment reads   // cycles per micro-step of the 3-piece tiles, summed over tiles
     KURBM_STAMP(ts[0]);
 #define KURBM_STAMP_OUT()                                                                         \
     do {                                                                                          \
         KURBM_STAMP(ts[5]);                                                                       \
         if (g.stamps && lane == 0) {                                                              \
-            unsigned long long* o = g.stamps + ((size_t)blockIdx.x * NWAVES + wave) * 16;         \
+            unsigned long long* o = g.stamps + ((size_t)blockIdx.x * (NT / 64) + wave) * 16;      \
             for (int q = 0; q < 6; ++q) o[q] = ts[q];                                             \
-            for (int q = 0; q < 5; ++q) o[8 + q] = tu[q + (q > 0)];                               \
-            for (int q = 0; q < 3; ++q) o[13 + q] = tv[q];                                        \
         }                                                                                         \
     } while (0)
 #else
@@ -109,28 +110,18 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_pb(GemmArgsB g) {
     const int bm = g.m_fastest ? tmn % g.grid_m : tmn / g.grid_n;
     const int bn = g.m_fastest ? tmn / g.grid_m : tmn - bm * g.grid_n;
     const int m0 = bm * BM, n0 = bn * BN;
-    const int col = n0 + 16 * wave + l15;     // the output column (= row of B) of this lane
 
     const int t_begin = z * g.kt_per_split;
     int t_end = t_begin + g.kt_per_split;
     if (t_end > g.kt_total) t_end = g.kt_total;
     const int nt = t_end > t_begin ? t_end - t_begin : 0;
-    // The workgroups of an XCD that share an operand tile (same bm: the A rows; same bn: the B rows) run in
-    // lockstep, so every line they need is missing from the XCD's L2 for all of them at the same moment and
-    // every load sees the Infinity-Cache latency.  Start each one a quarter of the k range apart: three
-    // quarters of a workgroup's lines were then brought into L2 by a neighbour a quarter loop earlier.
-    int rot = 0;
-    if (g.rotate) {
-        rot = ((bm + bn) & 3) * (nt >> 2);
-        if (g.seg_fastest) rot -= rot % g.nseg;
-    }
 
-    // A staging map: chunk q -> (row q / CPR, 16-B chunk q % CPR); rows outside the matrix are pointed
-    // at row 0 (they only feed outputs that are never stored).  B: row `col` of the mirror, k chunk `slot`.
-    // Loads are buffer loads: a per-lane BYTE offset that never changes (voffset) plus a per-tile scalar
-    // offset (soffset) against one of four descriptors -- no per-tile vector address arithmetic at all.
-    unsigned goffA[NA];
-    int soffA[NA];
+    // Staging map: chunk q -> (row q / CPR, 16-B chunk q % CPR); rows outside the matrix are pointed at
+    // row 0 (they only feed outputs that are never stored).  Loads are buffer loads: a per-lane BYTE
+    // offset that never changes (voffset) plus a per-tile scalar offset (soffset) against one descriptor
+    // per operand -- no per-tile vector address arithmetic at all.
+    unsigned goffA[NA], goffB[NB1];
+    int soffA[NA], soffB[NB1];
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
         const int q = it * NT + tid, row = q / CPR, ch = q % CPR;
@@ -138,22 +129,23 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_pb(GemmArgsB g) {
         goffA[it] = 2u * (unsigned)(x * g.lda + 8 * ch);
         soffA[it] = row * ROWB + 16 * ch;
     }
-    const unsigned goffB = 2u * (unsigned)((col < g.N ? col : 0) * g.ldb + 8 * slot);
+#pragma unroll
+    for (int it = 0; it < NB1; ++it) {
+        const int q = it * NT + tid, row = q / CPR, ch = q % CPR;
+        const int x = (n0 + row < g.N) ? n0 + row : 0;
+        goffB[it] = 2u * (unsigned)(x * g.ldb + 8 * ch);
+        soffB[it] = row * ROWB + 16 * ch;
+    }
     constexpr bool SIGNED = (EPI == EPI_SLAB);
     typedef __amdgpu_buffer_rsrc_t rsrc_t;
     const rsrc_t dA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.baseA), 0, 0xFFFFFFFF, 0x00020000);
     const rsrc_t dB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.baseB), 0, 0xFFFFFFFF, 0x00020000);
 
-    // a tile: the scalar byte offsets of its A chunk rows and of piece 0 of its B rows
+    // a tile: the scalar byte offsets of its A rows and of piece 0 of its B rows
     struct TileRef { uint32_t oa, ob, bplane; uint32_t flip; int npb; };
     auto tile_of = [&](int t) {
         TileRef r;
         t = t < t_end ? t : t_end - 1;
-        {   // rotated walk over the slice (see `rot`)
-            int tl = t - t_begin + rot;
-            if (tl >= nt) tl -= nt;
-            t = t_begin + tl;
-        }
         int seg, kt;
         if (g.seg_fastest) {
             kt = g.inv_nseg ? (int)__umulhi((uint32_t)t, g.inv_nseg) : t;       // inv == 0: divisor 1
@@ -173,141 +165,146 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_pb(GemmArgsB g) {
         return r;
     };
 
-    u32x4 ra[2][NA];        // A tiles in flight between global memory and LDS (fetched two tiles ahead)
-    u32x4 fb[2][PB][KS];    // B fragments of this tile and of the next, straight from global memory
-    u32x4 fa[2][TM];        // A fragments, by k-step
-    auto fetch_a = [&](u32x4 (&R)[NA], const TileRef& r) {
+    struct Regs { u32x4 a[NA], b[PB][NB1]; };
+    Regs r0, r1;   // two tiles in flight between global memory and LDS (fetched two tiles ahead)
+    // branch-free: a piece the segment does not use is fetched from the last one it does (same lines)
+    auto fetch = [&](Regs& R, const TileRef& r) {
 #pragma unroll
         for (int it = 0; it < NA; ++it)
-            R[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA, goffA[it], r.oa, 0));
-    };
-    // branch-free: a piece the segment does not use is fetched from the last one it does (same lines)
-    auto fetch_b = [&](u32x4 (&F)[PB][KS], const TileRef& r) {
+            R.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA, goffA[it], r.oa, 0));
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             const uint32_t so = __builtin_amdgcn_readfirstlane(r.ob + (uint32_t)(p < r.npb ? p : r.npb - 1) * r.bplane);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                F[p][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dB, goffB + 64u * ks, so, 0));
+            for (int it = 0; it < NB1; ++it)
+                R.b[p][it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dB, goffB[it], so, 0));
         }
     };
-    auto fetch_b_piece = [&](u32x4 (&F)[PB][KS], const TileRef& r, int p) {
-        const uint32_t so = __builtin_amdgcn_readfirstlane(r.ob + (uint32_t)(p < r.npb ? p : r.npb - 1) * r.bplane);
+    // park chunks [c0, c1) of the tile held in R: chunk order = A, piece 0 of B, piece 1, ...
+    constexpr int NCH = NA + PB * NB1;
+    auto park = [&](const Regs& R, int buf, const TileRef& r, int c0, int c1) {
+        unsigned char* a = smem + buf * STAGE;
+        unsigned char* b = a + A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            F[p][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dB, goffB + 64u * ks, so, 0));
-    };
-    auto park_a = [&](const u32x4 (&R)[NA], int buf, uint32_t flip) {
-        unsigned char* a = smem + buf * A_BYTES;
-#pragma unroll
-        for (int it = 0; it < NA; ++it) {
-            u32x4 v = R[it];
-            if (SIGNED) { v.x ^= flip; v.y ^= flip; v.z ^= flip; v.w ^= flip; }
-            *reinterpret_cast<u32x4*>(a + soffA[it]) = v;
+        for (int c = 0; c < NCH; ++c) {
+            if (c < c0 || c >= c1) continue;
+            if (c < NA) {
+                u32x4 v = R.a[c];
+                if (SIGNED) { v.x ^= r.flip; v.y ^= r.flip; v.z ^= r.flip; v.w ^= r.flip; }
+                *reinterpret_cast<u32x4*>(a + soffA[c]) = v;
+            } else {
+                const int p = (c - NA) / NB1, it = (c - NA) % NB1;
+                if (p < r.npb) *reinterpret_cast<u32x4*>(b + p * B1_BYTES + soffB[it]) = R.b[p][it];
+            }
         }
     };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 fa[2][TM], fb[2][TN];   // fragment double buffers: A by k-step, B by micro-step
     auto frag_a = [&](int buf, int ks, u32x4 (&f)[TM]) {
-        const unsigned char* c = smem + buf * A_BYTES + l15 * ROWB + 16 * slot + 64 * ks;
+        const unsigned char* c = smem + buf * STAGE + (wm * WM + l15) * ROWB + 16 * slot + 64 * ks;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
     };
-
-    f32x4 acc[TM];
+    auto frag_b = [&](int buf, int ks, int p, u32x4 (&f)[TN]) {
+        const unsigned char* c = smem + buf * STAGE + A_BYTES + p * B1_BYTES + (wn * WN + l15) * ROWB + 16 * slot + 64 * ks;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < TN; ++ni) f[ni] = *reinterpret_cast<const u32x4*>(c + ni * 16 * ROWB);
+    };
+    auto mfmas = [&](const u32x4 (&a)[TM], const u32x4 (&b)[TN]) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+    };
 
-    // One tile with NPB pieces = KS * NPB micro-steps of TM MFMAs (k-step ks = u / NPB, piece p = u % NPB):
-    //   u = 0        request the B fragments of tile i+1 and the A chunks of tile i+2; park the A chunks of
-    //                tile i+1 (requested a whole tile ago) in the other LDS buffer; read the A fragments of k-step 1
-    //   u = NPB      (first micro-step of k-step 1: the k-step-0 fragment registers are free)  the tile's ONLY
-    //                barrier, then read the NEXT tile's k-step-0 fragments -- half a tile before they are used
-    // Hazards: tile i+2 is parked into the buffer tile i is read from only at the next tile's u = 0, after
-    // this tile's barrier, which every wave reaches with its reads of that buffer (u = 0 here, u = NPB of the
-    // previous tile) complete.
-    auto one_tile = [&](const int cur, u32x4 (&RL)[NA], const u32x4 (&RP)[NA], const u32x4 (&FC)[PB][KS],
-                        u32x4 (&FN)[PB][KS], const TileRef& r1, const TileRef& r2, auto npb_tag) {
+    // One tile with NPB pieces = KS * NPB micro-steps (k-step ks = u / NPB, piece p = u % NPB), pipelined:
+    //   u = 0           request tile i+2 from global memory (registers L)
+    //   middle steps    park tile i+1 (registers P, requested a whole tile ago) in the other LDS buffer
+    //   last step       the tile's ONLY barrier, then read the NEXT tile's first fragments
+    // Every micro-step's fragment reads are issued one step ahead of the MFMAs that use them.
+    auto one_tile = [&](const int cur, Regs& L, const Regs& P, const TileRef& rp, const TileRef& r2, auto npb_tag) {
         constexpr int NPB = decltype(npb_tag)::value;
         constexpr int NU = KS * NPB;
-#ifdef KURBM_STAMPS
-        unsigned long long tq[7];
-        KURBM_STAMP(tq[0]);
-#endif
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             __builtin_amdgcn_sched_barrier(0);
-            const int ks = u / NPB, p = u % NPB;
-            // loads are SPREAD over the micro-steps (the L1 path takes ~25 cycles per 1-KiB wave load; eight of
-            // them issued back to back by all eight waves stall every wave for a thousand cycles)
-            if (u < NPB) fetch_b_piece(FN, r1, u);
-            if (PB > NPB && u == NPB - 1) {   // pieces this tile does not use may be needed by the next one
-#pragma unroll
-                for (int q = NPB; q < PB; ++q) fetch_b_piece(FN, r1, q);
+            if (u == 0) fetch(L, r2);
+            if constexpr (NU >= 4) {   // parks spread over the middle micro-steps
+                constexpr int NMID = NU - 2;
+                if (u >= 1 && u <= NMID) park(P, cur ^ 1, rp, (u - 1) * NCH / NMID, u * NCH / NMID);
+            } else {
+                if (u == 0) park(P, cur ^ 1, rp, 0, NCH);
             }
-            if (u == 0) {
-                park_a(RP, cur ^ 1, r1.flip);
-                frag_a(cur, 1, fa[1]);
-            }
-            if (u == 1) fetch_a(RL, r2);
-            if (u == NPB) {
+            const int ks = u / NPB;
+            if (u + 1 < NU) {
+                const int ksn = (u + 1) / NPB, pn = (u + 1) % NPB;
+                if (pn == 0) frag_a(cur, ksn, fa[ksn & 1]);
+                frag_b(cur, ksn, pn, fb[(u + 1) & 1]);
+            } else {
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
                 frag_a(cur ^ 1, 0, fa[0]);
+                frag_b(cur ^ 1, 0, 0, fb[0]);
             }
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks & 1][mi]),
-                                                                  __builtin_bit_cast(bf16x8, FC[p][ks]), acc[mi], 0, 0, 0);
-#ifdef KURBM_STAMPS
-            KURBM_STAMP(tq[u + 1]);
-            if (NPB == 3) tu[u] += tq[u + 1] - tq[u];
-#endif
+            mfmas(fa[ks & 1], fb[u & 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto tile_any = [&](const int cur, u32x4 (&RL)[NA], const u32x4 (&RP)[NA], const u32x4 (&FC)[PB][KS],
-                        u32x4 (&FN)[PB][KS], int npb, const TileRef& r1, const TileRef& r2) {
-        if (PB >= 3 && npb == 3) one_tile(cur, RL, RP, FC, FN, r1, r2, std::integral_constant<int, 3>{});
-        else if (PB >= 2 && npb == 2) one_tile(cur, RL, RP, FC, FN, r1, r2, std::integral_constant<int, 2>{});
-        else one_tile(cur, RL, RP, FC, FN, r1, r2, std::integral_constant<int, 1>{});
+    auto tile_any = [&](const int cur, Regs& L, const Regs& P, int npb, const TileRef& rp, const TileRef& r2) {
+        if (PB >= 3 && npb == 3) one_tile(cur, L, P, rp, r2, std::integral_constant<int, 3>{});
+        else if (PB >= 2 && npb == 2) one_tile(cur, L, P, rp, r2, std::integral_constant<int, 2>{});
+        else one_tile(cur, L, P, rp, r2, std::integral_constant<int, 1>{});
     };
 
     if (nt > 0) {
-        TileRef rc = tile_of(t_begin), r1 = tile_of(t_begin + 1);
-        fetch_a(ra[0], rc);
-        fetch_b(fb[0], rc);
-        park_a(ra[0], 0, rc.flip);
-        fetch_a(ra[1], r1);
+        TileRef rc = tile_of(t_begin), rn = tile_of(t_begin + 1);
+        fetch(r0, rc);
+        park(r0, 0, rc, 0, NCH);
+        fetch(r1, rn);
         __syncthreads();
         frag_a(0, 0, fa[0]);
+        frag_b(0, 0, 0, fb[0]);
         KURBM_STAMP(ts[1]);
         // unrolled by two: register sets and LDS buffers alternate statically.  Branch-free: past the
         // end of the slice the last tile is fetched / parked again (in bounds, never read).
         int i = 0;
         for (; i + 1 < nt; i += 2) {
             TileRef r2 = tile_of(t_begin + i + 2);
-            tile_any(0, ra[0], ra[1], fb[0], fb[1], rc.npb, r1, r2);
-            rc = r1; r1 = r2;
+            tile_any(0, r0, r1, rc.npb, rn, r2);
+            rc = rn; rn = r2;
             r2 = tile_of(t_begin + i + 3);
-            tile_any(1, ra[1], ra[0], fb[1], fb[0], rc.npb, r1, r2);
-            rc = r1; r1 = r2;
+            tile_any(1, r1, r0, rc.npb, rn, r2);
+            rc = rn; rn = r2;
         }
         if (i < nt) {
             const TileRef r2 = tile_of(t_begin + i + 2);
-            tile_any(0, ra[0], ra[1], fb[0], fb[1], rc.npb, r1, r2);
+            tile_any(0, r0, r1, rc.npb, rn, r2);
         }
     }
     __syncthreads();
     KURBM_STAMP(ts[2]);
 
     // ---------------- epilogue: raw partial sums to a slab (statistics GEMM), through an fp32 patch ----
+    // C layout: acc[mi][ni][r] is row m0 + wm WM + 16 mi + 4 slot + r, column n0 + wn WN + 16 ni + l15.
     if (EPI == EPI_SLAB) {
         float* slab = g.slab + (size_t)z * g.slab_stride;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<float*>(smem + (mi * 16 + slot * 4 + r) * PROW32 + 4 * (16 * wave + l15)) =
-                    (col < g.N) ? acc[mi][r] : 0.f;
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<float*>(smem + (wm * WM + mi * 16 + slot * 4 + r) * PROW32 +
+                                              4 * (wn * WN + ni * 16 + l15)) =
+                        (n0 + wn * WN + ni * 16 + l15 < g.N) ? acc[mi][ni][r] : 0.f;
         __syncthreads();
         constexpr int CH = BN / 4;   // 16-B chunks per row
 #pragma unroll
@@ -324,37 +321,40 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_pb(GemmArgsB g) {
     }
 
     // ---------------- epilogue of a half step ------------------------------------------------
-    // C layout: acc[mi][r] is row m0 + 16 mi + 4 slot + r, column `col`.
-    float xv[TM][4];   // the value plane: the sample, or the probability when nothing is drawn
-    int colx = col;
-    asm volatile("" : "+v"(colx));   // opaque: keeps the epilogue's address arithmetic out of the k loop's registers
-#define col colx
-    const bool col_ok = col < g.N;
+    float xv[TM][TN][4];   // the value plane: the sample, or the probability when nothing is drawn
+    int colb = n0 + wn * WN + l15;
+    asm volatile("" : "+v"(colb));   // opaque: keeps the epilogue's address arithmetic out of the k loop's registers
+    const int rowq = m0 + wm * WM + slot * 4;
     {
-        const float bias = (col < g.N) ? g.bias[col] : 0.f;
         auto elementwise = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const int rowb = m0 + mi * 16 + slot * 4;
-                uint32_t w[4] = {0u, 0u, 0u, 0u};
-                if (NOISE != NOISE_NONE) {
-                    const uint64_t grow = g.rng.row0 + (uint64_t)rowb;
-                    philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step, g.rng.seed_lo,
-                                  g.rng.seed_hi, w);
-                }
+            for (int ni = 0; ni < TN; ++ni) {
+                const int col = colb + ni * 16;
+                const bool col_ok = col < g.N;
+                const float bias = col_ok ? g.bias[col] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float x = acc[mi][r] + bias;
-                    float p;
-                    if (ACT == ACT_SIGMOID) p = sigmoidf_fast(x);
-                    else if (ACT == ACT_RELU) p = fmaxf(x, 0.f);
-                    else p = x;
-                    const float ua = u32_to_unit(w[r]);
-                    xv[mi][r] = (NOISE == NOISE_BERNOULLI) ? ((ua < p) ? 1.0f : 0.0f) : p;
-                    if (NOISE != NOISE_NONE && col_ok && rowb + r < g.M) {   // test planes: 16 lanes x 4 B per row
-                        if (g.prob_f32) g.prob_f32[(size_t)(rowb + r) * g.ldo32 + col] = p;
-                        if (g.out_u) g.out_u[(size_t)(rowb + r) * g.ldo32 + col] = ua;
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int rowb = rowq + mi * 16;
+                    uint32_t w[4] = {0u, 0u, 0u, 0u};
+                    if (NOISE != NOISE_NONE) {
+                        const uint64_t grow = g.rng.row0 + (uint64_t)rowb;
+                        philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step, g.rng.seed_lo,
+                                      g.rng.seed_hi, w);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = acc[mi][ni][r] + bias;
+                        float p;
+                        if (ACT == ACT_SIGMOID) p = sigmoidf_fast(x);
+                        else if (ACT == ACT_RELU) p = fmaxf(x, 0.f);
+                        else p = x;
+                        const float ua = u32_to_unit(w[r]);
+                        xv[mi][ni][r] = (NOISE == NOISE_BERNOULLI) ? ((ua < p) ? 1.0f : 0.0f) : p;
+                        if (NOISE != NOISE_NONE && g.side && col_ok && rowb + r < g.M) {   // test planes
+                            if (g.prob_f32) g.prob_f32[(size_t)(rowb + r) * g.ldo32 + col] = p;
+                            if (g.out_u) g.out_u[(size_t)(rowb + r) * g.ldo32 + col] = ua;
+                        }
                     }
                 }
             }
@@ -365,38 +365,46 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_pb(GemmArgsB g) {
     }
     KURBM_STAMP(ts[3]);
 
-    // (a) column sums of the value plane over the tile's rows: this wave holds whole columns
+    // (a) column sums of the value plane over this wave's WM rows of the tile: row (bm * WAVES_M + wm) of colpart
     if (g.colpart) {
-        float cs = 0.f;
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+        for (int ni = 0; ni < TN; ++ni) {
+            float cs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (m0 + mi * 16 + slot * 4 + r < g.M) cs += xv[mi][r];
-        cs += __shfl_xor(cs, 16);
-        cs += __shfl_xor(cs, 32);
-        if (slot == 0 && col_ok) g.colpart[(size_t)bm * g.ld_colpart + col] = g.colsign * cs;
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rowq + mi * 16 + r < g.M) cs += xv[mi][ni][r];
+            cs += __shfl_xor(cs, 16);
+            cs += __shfl_xor(cs, 32);
+            const int col = colb + ni * 16;
+            if (slot == 0 && col < g.N) g.colpart[(size_t)(bm * WAVES_M + wm) * g.ld_colpart + col] = g.colsign * cs;
+        }
     }
 
     // (b) transposed bf16 plane(s) [N][ldoT]: 4 consecutive rows of this lane's column = one 8-byte store;
     //     rows past M (k padding of the statistics GEMM) are written as zeros
-    if (g.outT && col_ok) {
+    if (g.outT) {
         const int np = (g.outT_pieces == 3) ? 3 : 1;
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const int rb = m0 + mi * 16 + slot * 4;
-            if (rb < g.ldoT) {
-                float v[4];
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = colb + ni * 16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (rb + r < g.M) ? xv[mi][r] : 0.f;
-                uint16_t* dst = g.outT + (size_t)col * g.ldoT + rb;
-                for (int j = 0; j < np; ++j) {
-                    u32x2 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>(dst + j * g.outT_plane) = pk;
-                    if (j + 1 < np) {   // residual of the piece just written: exact in fp32
-                        v[0] -= bf16_bits_to_f32(pk.x & 0xFFFFu); v[1] -= bf16_bits_to_f32(pk.x >> 16);
-                        v[2] -= bf16_bits_to_f32(pk.y & 0xFFFFu); v[3] -= bf16_bits_to_f32(pk.y >> 16);
+            for (int mi = 0; mi < TM; ++mi) {
+                const int rb = rowq + mi * 16;
+                if (col < g.N && rb < g.ldoT) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (rb + r < g.M) ? xv[mi][ni][r] : 0.f;
+                    uint16_t* dst = g.outT + (size_t)col * g.ldoT + rb;
+                    for (int j = 0; j < np; ++j) {
+                        u32x2 pk;
+                        pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<u32x2*>(dst + j * g.outT_plane) = pk;
+                        if (j + 1 < np) {   // residual of the piece just written: exact in fp32
+                            v[0] -= bf16_bits_to_f32(pk.x & 0xFFFFu); v[1] -= bf16_bits_to_f32(pk.x >> 16);
+                            v[2] -= bf16_bits_to_f32(pk.y & 0xFFFFu); v[3] -= bf16_bits_to_f32(pk.y >> 16);
+                        }
                     }
                 }
             }
@@ -404,14 +412,16 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_pb(GemmArgsB g) {
     }
 
     // (c) fp32 copy of the value plane (persistent chain, test hooks): 16 lanes x 4 B per row
-    if (g.out_f32 && col_ok) {
+    if (g.out_f32) {
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+        for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + mi * 16 + slot * 4 + r;
-                if (row < g.M) g.out_f32[(size_t)row * g.ldo32 + col] = xv[mi][r];
-            }
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rowq + mi * 16 + r, col = colb + ni * 16;
+                    if (row < g.M && col < g.N) g.out_f32[(size_t)row * g.ldo32 + col] = xv[mi][ni][r];
+                }
     }
 
     // (d) row-major bf16 plane [M][ldo]: neighbouring lanes hold neighbouring columns; pair them up (even
@@ -420,16 +430,20 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_pb(GemmArgsB g) {
     if (g.out) {
         const int odd = l15 & 1;
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+        for (int ni = 0; ni < TN; ++ni) {
+            const bool col_ok = colb + ni * 16 < g.N;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float mine = col_ok ? (odd ? xv[mi][2 * h + 1] : xv[mi][2 * h]) : 0.f;
-                const float send = col_ok ? (odd ? xv[mi][2 * h] : xv[mi][2 * h + 1]) : 0.f;
-                const float recv = __shfl_xor(send, 1);
-                const uint32_t pk = odd ? pack_bf16x2(recv, mine) : pack_bf16x2(mine, recv);
-                *reinterpret_cast<uint32_t*>(smem + (mi * 16 + slot * 4 + 2 * h + odd) * PROW16 +
-                                             2 * (16 * wave + (l15 & ~1))) = pk;
-            }
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float mine = col_ok ? (odd ? xv[mi][ni][2 * h + 1] : xv[mi][ni][2 * h]) : 0.f;
+                    const float send = col_ok ? (odd ? xv[mi][ni][2 * h] : xv[mi][ni][2 * h + 1]) : 0.f;
+                    const float recv = __shfl_xor(send, 1);
+                    const uint32_t pk = odd ? pack_bf16x2(recv, mine) : pack_bf16x2(mine, recv);
+                    *reinterpret_cast<uint32_t*>(smem + (wm * WM + mi * 16 + slot * 4 + 2 * h + odd) * PROW16 +
+                                                 2 * (wn * WN + ni * 16 + (l15 & ~1))) = pk;
+                }
+        }
         __syncthreads();
         constexpr int CH = BN / 8;   // 16-B chunks per row
 #pragma unroll
@@ -443,7 +457,6 @@ __global__ __launch_bounds__(64 * NWAVES) void k_gemm_pb(GemmArgsB g) {
     }
     KURBM_STAMP(ts[4]);
     KURBM_STAMP_OUT();
-#undef col
 }
 
 // ------------------------------------------------------------------------------------
@@ -469,14 +482,11 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
         if (oa0 > lim || oa1 > lim || ob0 > lim || ob1 > lim) return hipErrorInvalidValue;
         g.offA0 = (uint32_t)oa0; g.offA1 = (uint32_t)oa1; g.offB0 = (uint32_t)ob0; g.offB1 = (uint32_t)ob1;
     }
-    {
-        static const int rotate = getenv("KURBM_X3_ROTATE") ? atoi(getenv("KURBM_X3_ROTATE")) : 1;
-        g.rotate = rotate;
-    }
+    g.side = (g.prob_f32 != nullptr) || (g.out_u != nullptr);
     const int nblk = g.grid_m * g.grid_n * g.nsplit;
 #define KURBM_PB(E, NZ)                                                                              \
     if (epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) {                                          \
-        hipLaunchKernelGGL((k_gemm_pb<8, 64, 3, E, NZ>), dim3(nblk), dim3(512), 0, st, g);           \
+        hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, 3, E, NZ>), dim3(nblk), dim3(512), 0, st, g); \
         return hipGetLastError();                                                                    \
     }
     KURBM_PB(EPI_HALFSTEP, NOISE_NONE)

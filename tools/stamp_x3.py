@@ -37,9 +37,7 @@ def report(name, s):
         ok = (a > 0) & (b > 0)
         d.append(np.median((b - a)[ok]) if ok.any() else 0.0)
     end = s[:, 5].max() - t0
-    print("%-10s wgs %4d | " % (name, len(s)) + "  ".join("%s %6.0f" % (n, x) for n, x in zip(NAMES[1:], d[1:]))
-          + " | u0, u2..u5: " + " ".join("%6.0f" % x for x in np.median(s[:, 8:13], axis=0))
-          + " | in u0: loads, park, frag reads: " + " ".join("%6.0f" % x for x in np.median(s[:, 13:16], axis=0)))
+    print("%-10s wgs %4d | " % (name, len(s)) + "  ".join("%s %6.0f" % (n, x) for n, x in zip(NAMES[1:], d[1:])))
 
 
 step = lambda: eng.cd_step(V, B, 0, 1e-3 / B, 42, 0, compute="x3")
@@ -54,6 +52,4 @@ lib.kurbm_debug_set_stamp_buffer(None)
 s = buf.cpu().numpy().astype(np.float64).reshape(4, 512, 8, 16)
 for n, name in enumerate(("vh sample", "hv sample", "vh prob", "statistics")):
     report(name, s[n, :, 0])
-    if n == 0:
-        for wv in range(8):
-            report("  wave %d" % wv, s[n, :, wv])
+
