@@ -4,7 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): CD-1 Gibbs-steps/sec on a 784-visible x 1024-hidden RBM at batch 4096,
-fp32, synthetic binary data resident in HBM.  One "step" (the unit of `value`) = one full CD-1
+fp32, synthetic binary data resident in HBM.  --compute picks how the matrix products run: "x3"
+(default: fp32 values carried as exact bf16 triples on the bf16 matrix cores, fp32 accumulate --
+results held to the fp32 oracle and the fp32 tolerances by tests/test_gpu_parity.py::test_x3_*) or
+"fp32" (fp32 MFMA).  Rank 0 times BOTH paths after the timed region and reports them under `paths`.  One "step" (the unit of `value`) = one full CD-1
 parameter update over 4096 rows: h_pos sample, v_neg sample, h_neg probabilities, dW / db_h / db_v
 applied (update_mode "fused").  With N > 1 every rank processes its own 4096 rows per step (weak
 scaling: global batch 4096 N, config 3 at N = 8), the packed [dW|db_h|db_v] sums are all-reduced
@@ -30,6 +33,7 @@ if ROOT not in sys.path:
 
 N_VIS, N_HID, BATCH = 784, 1024, 4096
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CU x 256 flop/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16
 FLOP_HALF = 2.0 * BATCH * N_VIS * N_HID            # one half-step GEMM
 FLOP_OUTER = 4.0 * BATCH * N_VIS * N_HID           # statistics GEMM: k = 2 x batch
 FLOP_STEP = 3 * FLOP_HALF + FLOP_OUTER             # 10 B V H
@@ -76,6 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compute", choices=("x3", "fp32"), default=os.environ.get("BENCH_COMPUTE", "x3"))
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,9 +121,9 @@ def main():
     def step(i):
         lo = (i % n_batches) * BATCH
         if world == 1 and not force_dp:
-            eng.cd_step(V, BATCH, lo, lr, seed, i)
+            eng.cd_step(V, BATCH, lo, lr, seed, i, compute=args.compute)
         else:
-            eng.cd_step(V, BATCH, lo, lr, seed, i, apply=False, emit_delta=True, row0=rank * BATCH)
+            eng.cd_step(V, BATCH, lo, lr, seed, i, apply=False, emit_delta=True, row0=rank * BATCH, compute=args.compute)
             dp.allreduce_sum_(eng.delta_buffer())
             eng.apply_delta(lr)
 
@@ -172,30 +177,65 @@ def main():
                                ("outer_stats_gemm_plus_reduce", k_outred, FLOP_OUTER)):
             ms = event_time_ms(fn, 50)
             kern[name] = {"ms": ms, "tflops": flop / (ms * 1e-3) / 1e12, "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
-        dom = max((k for k in kern if k != "outer_stats_gemm_plus_reduce"), key=lambda k: kern[k]["ms"])
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-        # (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE; profiles/*_hbm_traffic.json)
-        traffic = None
+        # the x3 launches, each alone, replayed on the planes of a complete x3 step (kurbm_cd_step_x3_stage)
+        eng.cd_step(V, BATCH, 0, lr, seed, 0, compute="x3")
+        x3_exec = {"x3_half_step_vh_sample": 3 * FLOP_HALF, "x3_half_step_hv_sample": 3 * FLOP_HALF,
+                   "x3_half_step_vh_prob": 3 * FLOP_HALF, "x3_stats_gemm": 4 * FLOP_HALF}     # executed bf16 flop (pieces)
+        x3_algo = {"x3_half_step_vh_sample": FLOP_HALF, "x3_half_step_hv_sample": FLOP_HALF,
+                   "x3_half_step_vh_prob": FLOP_HALF, "x3_stats_gemm": FLOP_OUTER}
+        kern_x3 = {}
+        for name, stage in (("x3_vpos_to_bf16", 0), ("x3_half_step_vh_sample", 1), ("x3_half_step_hv_sample", 2),
+                            ("x3_half_step_vh_prob", 3), ("x3_stats_gemm", 4), ("x3_reduce_apply_plus_mirror", 5)):
+            ms = event_time_ms(lambda stage=stage: eng.cd_step_x3_stage(V, BATCH, 0, lr, seed, 0, stage), 50)
+            kern_x3[name] = {"ms": ms}
+            if name in x3_exec:
+                kern_x3[name].update({"executed_bf16_tflops": x3_exec[name] / (ms * 1e-3) / 1e12,
+                                      "frac_of_bf16_peak": x3_exec[name] / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                                      "algorithmic_tflops": x3_algo[name] / (ms * 1e-3) / 1e12})
+        # both compute paths, same batch, HIP events (single GPU, local step)
+        paths = {}
+        for c in ("x3", "fp32"):
+            ms = event_time_ms(lambda c=c: eng.cd_step(V, BATCH, 0, lr, seed, 0, compute=c), 100, warm=10)
+            tf = FLOP_STEP / (ms * 1e-3) / 1e12
+            paths[c] = {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "algorithmic_tflops": tf,
+                        "frac_of_fp32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS}
+        traffic_all = {}
         try:
             import glob
-            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
-            if tf:
-                traffic = json.load(open(tf[-1])).get(dom, {}).get("hbm_bytes_per_launch")
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+                traffic_all.update(json.load(open(f)))      # later files win
         except Exception:
-            traffic = None
+            traffic_all = {}
+        if args.compute == "x3":
+            dom = max(x3_exec, key=lambda k: kern_x3[k]["ms"])
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": kern_x3[dom]["executed_bf16_tflops"],
+                        "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": kern_x3[dom]["frac_of_bf16_peak"],
+                        "note": "executed bf16 MFMA flop (the pieces: 3 per half step, 1 + 3 for the statistics) against the dense "
+                                "bf16 peak; algorithmic fp32 flop/s of the same launch in kernels[...].algorithmic_tflops",
+                        "traffic": traffic_all.get(dom, {}).get("hbm_bytes_per_launch"),
+                        "kernels": kern_x3, "kernels_fp32_path": kern}
+        else:
+            dom = max((k for k in kern if k != "outer_stats_gemm_plus_reduce"), key=lambda k: kern[k]["ms"])
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": kern[dom]["frac"],
+                        "traffic": traffic_all.get(dom, {}).get("hbm_bytes_per_launch"),
+                        "kernels": kern, "kernels_x3_path": kern_x3}
         step_tflops = FLOP_STEP / (ms_per_step * 1e-3) / 1e12
+        roofline["step_algorithmic_tflops"] = step_tflops * world
+        roofline["step_frac_of_fp32_mfma_peak"] = step_tflops / PEAK_F32_MFMA_TFLOPS
+        dtype = ("f32 (storage, accumulation, results); products as exact bf16 triples on the bf16 MFMA (x3)"
+                 if args.compute == "x3" else "f32")
         out = {
             "metric": "cd1_gibbs_steps_per_sec", "value": value,
             "unit": "steps/s (1 step = CD-1 update over 4096 rows, 784x1024 fp32)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "rbm_784x1024_cd1_batch4096_fp32 (BASELINE.json configs[1]%s)" % ("" if world == 1 else "; configs[2] shape: 4096 rows per GPU"),
                        "n_vis": N_VIS, "n_hid": N_HID, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "cd_k": 1, "update_mode": "fused", "lr": "1e-3/4096", "parallelism": "dp%d" % world,
-                       "flop_per_step": FLOP_STEP},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": kern[dom]["frac"], "traffic": traffic,
-                         "kernels": kern, "step_tflops": step_tflops * world, "step_frac": step_tflops / PEAK_F32_MFMA_TFLOPS},
+                       "compute": args.compute, "flop_per_step": FLOP_STEP},
+            "paths": paths,
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -246,6 +246,17 @@ int kurbm_cd_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t
                      const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts,
                      int which, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
 
+/*
+ * Measurement hook: ONE launch of the kurbm_cd_step_x3 sequence, on the planes a previous complete
+ * step left in `workspace` (same arguments as that step).  stage: 0 v_pos -> bf16 pieces, 1 h_pos half
+ * step, 2 v_neg half step(s), 3 h_neg half step, 4 statistics GEMM, 5 slab reduction + parameter
+ * update + mirror refresh, 6 mirror refresh alone.  bench.py times the kernels of a step with it.
+ */
+int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                           const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts,
+                           int which, int stage, void* workspace, size_t workspace_bytes,
+                           kurbm_stream_t stream);
+
 /* One half step on the x3 path (transform / test hook): dir 0 = v->h, 1 = h->v. */
 int kurbm_half_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, int dir,
                        const float* in, int in_pieces, int rows, int ld_in, int act, int noise,

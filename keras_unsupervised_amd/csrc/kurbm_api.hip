@@ -746,7 +746,10 @@ static int half_step_any(kurbm_ctx* ctx, int pieces, int in_pieces, const kurbm_
 
 static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                        const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace,
-                       size_t workspace_bytes, kurbm_stream_t stream) {
+                       size_t workspace_bytes, kurbm_stream_t stream, int only = -1) {
+    // `only` >= 0 (measurement hook kurbm_cd_step_x3_stage): launch just that stage of the sequence, on
+    // the planes a previous complete step left in the workspace
+#define KURBM_STAGE(n) (only < 0 || only == (n))
     if (!ctx || !o) return fail(KURBM_ERR_ARG, "null argument");
     if (int e = check_params(p)) return e;
     if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
@@ -778,18 +781,19 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     // (x3: plus the column sums of v_pos per 32-row band, the positive half of the visible-bias statistics)
     const bool pb = (pieces == 3) && !env_int("KURBM_X3_SEGMENTS", 0);
     const int gp_v = pb ? ceil_div(rows, 32) : 0;
-    HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Lv, w.Kb, w.vbT, w.Lb, p->n_vis, v_pieces, w.planeV,
-                               w.planeVT, pb ? w.part_v : nullptr, w.ldv32, st));
+    if (KURBM_STAGE(0))
+        HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Lv, w.Kb, w.vbT, w.Lb, p->n_vis, v_pieces, w.planeV,
+                                   w.planeVT, pb ? w.part_v : nullptr, w.ldv32, st));
     // h_pos ~ p(h | v_pos)                                          rbm.py:120
     RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
-    {
+    if (KURBM_STAGE(1)) {
         HalfOutB ho;
         ho.out = w.hb; ho.ldo = w.Lh; ho.outT = w.hbT; ho.ldoT = w.Lb;
         if (pb) { ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.colsign = 1.f; }
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
     }
     const uint16_t* h_cur = w.hb;
-    if (o->v_chain) {   // persistent chain: negative phase starts from the stored fantasy particles
+    if (o->v_chain && KURBM_STAGE(1)) {   // persistent chain: negative phase starts from the stored fantasy particles
         HIP_TRY(launch_f32_to_bf16(o->v_chain, rows, p->n_vis, ldv, w.cb, w.Lv, w.Kb, nullptr, 0, 0, v_pieces, w.planeV, 0, nullptr, 0, st));
         r = make_rng(o->seed, o->row0, base + 32u, o->step);
         HalfOutB ho;
@@ -797,11 +801,11 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.cb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
         h_cur = w.h2b;
     }
-    int gm_v = 0, gm_h = 0;
+    int gm_v = ceil_div(rows, 128), gm_h = gm_v;   // row tiles of the half steps (bias partial rows)
     for (int t = 1; t <= o->k; ++t) {
         const bool last = (t == o->k);
         r = make_rng(o->seed, o->row0, base + 2u * t - 1u, o->step);      // v_t ~ p(v | h_{t-1})   rbm.py:121-123
-        {
+        if (KURBM_STAGE(2)) {
             HalfOutB ho;
             ho.out = w.v2b; ho.ldo = w.Lv;
             if (last) {
@@ -817,7 +821,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             }
             if ((e = half_step_b(ctx, LAYOUT_HV, p, m, h_cur, w.Lh, 1, 0, rows, act_v, noise_v, &r, ho, st))) return e;
         }
-        if (!last) {
+        if (!last && KURBM_STAGE(2)) {
             r = make_rng(o->seed, o->row0, base + 2u * t, o->step);
             HalfOutB ho;
             ho.out = w.h2b; ho.ldo = w.Lh;
@@ -826,7 +830,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         }
     }
     // h_neg = sigmoid(v_neg.W + b_h), probabilities (rbm.py:124): only its transposed image is needed
-    {
+    if (KURBM_STAGE(3)) {
         HalfOutB ho;
         ho.outT = w.hnT; ho.ldoT = w.Lb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT;
         ho.ref16 = w.hb; ho.ldref16 = w.Lh;
@@ -839,7 +843,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     // segments: (piece of v_pos) x h_pos, then v_neg x (piece of h_neg), negated
     const OuterPlanB pl = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, pieces == 3 ? v_pieces + 1 : 2, pieces == 3);
     int nslab_used = pl.nsplit;
-    if (need_w) {
+    if (need_w && KURBM_STAGE(4)) {
         GemmArgsB g;
         memset(&g, 0, sizeof g);
         g.A0 = w.vbT; g.a_plane0 = w.planeVT; g.B0 = w.hbT;
@@ -852,6 +856,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             g.nseg = pb_codes(v_pieces, 1, 0u, &g.seg_codes, 0);
             g.nseg = pb_codes(1, 3, 1u, &g.seg_codes, g.nseg);
             g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
+            g.m_fastest = env_int("KURBM_X3_STATS_MFAST", 0);
             g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
             g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
             HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
@@ -882,10 +887,11 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     a.part_v = w.part_v; a.nrow_tiles_v = pb ? gp_v + 2 * gm_v : gm_v; a.ld_part_v = w.ldv32;
     a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
     a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
-    HIP_TRY(launch_reduce_apply(a, st));
-    if (a.W)   // the fp32 master moved: re-derive both mirrors
+    if (KURBM_STAGE(5)) HIP_TRY(launch_reduce_apply(a, st));
+    if (a.W && (KURBM_STAGE(5) || only == 6))   // the fp32 master moved: re-derive both mirrors
         HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, pieces,
                                    m.planeW, m.planeWt, nullptr, 0, st));
+#undef KURBM_STAGE
     return KURBM_OK;
 }
 
@@ -942,6 +948,14 @@ int kurbm_cd_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t
                      int v_pieces, int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace,
                      size_t workspace_bytes, kurbm_stream_t stream) {
     return cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, which, workspace, workspace_bytes, stream);
+}
+
+int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
+                           int v_pieces, int rows, int ldv, const kurbm_cd_opts* o, int which, int stage, void* workspace,
+                           size_t workspace_bytes, kurbm_stream_t stream) {
+    if (stage < 0 || stage > 6) return fail(KURBM_ERR_ARG, "stage must be in [0, 6]");
+    return cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, which, workspace, workspace_bytes, stream,
+                       stage);
 }
 
 int kurbm_bf16_exact(kurbm_ctx* ctx, const float* x, int rows, int cols, int ld, int* flag, kurbm_stream_t stream) {

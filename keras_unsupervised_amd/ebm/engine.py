@@ -255,6 +255,19 @@ class DeviceRBM:
             else:
                 raise ValueError("compute must be 'fp32', 'x3' or 'bf16', got %r" % (compute,))
 
+    def cd_step_x3_stage(self, v, rows, row_start, lr, seed, step, stage):
+        """Measurement hook (bench.py): ONE launch of the x3 CD-1 sequence on the planes the previous
+        complete x3 step left in the workspace; stage numbering as kurbm_cd_step_x3_stage."""
+        with torch.cuda.device(self.device):
+            vp = self.v_pieces(v)
+            mir, ws = self.mirror(3), self.workspace_bf16(rows, 1, 3, vp)
+            opts = CdOpts(1, MODE_VISIBLE_BERNOULLI, float(lr), 1, None, None, int(seed), 0, int(step) & 0xFFFFFFFF, 0)
+            check(self.lib.kurbm_cd_step_x3_stage(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                                  v.ptr(row_start), vp, rows, v.ld, C.byref(opts), WHICH_ALL, int(stage),
+                                                  ws.data_ptr(), ws.numel(), self._stream()))
+            if stage == 5:
+                self._weights_written(kept=3)
+
     def cd_epoch(self, v, n_rows, batch_size, lr, seed, step0, k=1, mode=MODE_VISIBLE_BERNOULLI, v_chain=None):
         """All batches of one epoch in ONE library call (fp32, fused updates, no score); returns #steps."""
         with torch.cuda.device(self.device):
