@@ -550,11 +550,12 @@ struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_spli
 // fastest, so a slice is a whole number of k positions
 static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, bool pb) {
     OuterPlanB pl;
+    const bool bn64 = pb && env_int("KURBM_X3_BN", 128) == 64;
     pl.gm = ceil_div(n_vis, 128);
-    pl.gn = ceil_div(n_hid, 128);
+    pl.gn = ceil_div(n_hid, bn64 ? 64 : 128);
     pl.nkt = round_up(rows, 128) / (pb ? 64 : 128);
     pl.kt_total = nseg * pl.nkt;
-    int s = env_int("KURBM_BF16_SPLIT", ((pb ? 1 : 2) * ctx->ncu) / (pl.gm * pl.gn));
+    int s = env_int("KURBM_BF16_SPLIT", ((pb && !bn64 ? 1 : 2) * ctx->ncu) / (pl.gm * pl.gn));
     if (s < 1) s = 1;
     if (s > pl.nkt) s = pl.nkt;
     pl.nsplit_bound = s;
@@ -655,7 +656,8 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
     if (m.pieces == 3 && !env_int("KURBM_X3_SEGMENTS", 0)) {
         // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip), 128 x 128 tiles
         g.nseg = pb_codes(a_pieces, 3, 0u, &g.seg_codes, 0);
-        g.grid_m = ceil_div(rows, 128); g.grid_n = ceil_div(g.N, 128);
+        g.cfg = env_int("KURBM_X3_BN", 128) == 64 ? 1 : 0;     // 1: 128 x 64 tiles, 256 threads, two workgroups per CU
+        g.grid_m = ceil_div(rows, 128); g.grid_n = ceil_div(g.N, g.cfg ? 64 : 128);
         g.nkt = g.K / 64;
         g.inv_nkt = inv_of(g.nkt);
         g.kt_total = g.nseg * g.nkt; g.kt_per_split = g.kt_total; g.nsplit = 1;
@@ -857,6 +859,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             g.nseg = pb_codes(1, 3, 1u, &g.seg_codes, g.nseg);
             g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
             g.m_fastest = env_int("KURBM_X3_STATS_MFAST", 0);
+            g.cfg = env_int("KURBM_X3_BN", 128) == 64 ? 1 : 0;
             g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
             g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
             HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));

@@ -60,7 +60,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int PB, int EPI, int NOISE>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_pb(GemmArgsB g) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB g) {   // two waves per SIMD either way
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     // LDS rows are the bare 128-byte k-tile, their eight 16-byte chunks XOR-swizzled with (row >> 1) & 7.
     // ds_read_b128 is served in groups of 16 lanes that are NOT consecutive ({0-3, 12-15, 20-27}, ...;
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_pb(GemmArgsB g)
     const int l15 = lane & 15, slot = lane >> 4;
 #ifdef KURBM_STAMPS
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tu[6] = {0, 0, 0, 0, 0, 0};   // cycles per micro-step of the 3-piece tiles, summed over tiles
     KURBM_STAMP(ts[0]);
 #define KURBM_STAMP_OUT()                                                                         \
     do {                                                                                          \
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_pb(GemmArgsB g)
         if (g.stamps && lane == 0) {                                                              \
             unsigned long long* o = g.stamps + ((size_t)blockIdx.x * (NT / 64) + wave) * 16;      \
             for (int q = 0; q < 6; ++q) o[q] = ts[q];                                             \
+            for (int q = 0; q < 6; ++q) o[8 + q] = tu[q];                                         \
         }                                                                                         \
     } while (0)
 #else
@@ -242,6 +244,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_pb(GemmArgsB g)
     auto one_tile = [&](const int cur, Regs& L, const Regs& P, const TileRef& rp, const TileRef& r2, auto npb_tag) {
         constexpr int NPB = decltype(npb_tag)::value;
         constexpr int NU = KS * NPB;
+#ifdef KURBM_STAMPS
+        unsigned long long tq[7];
+        KURBM_STAMP(tq[0]);
+#endif
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             __builtin_amdgcn_sched_barrier(0);
@@ -264,6 +270,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_pb(GemmArgsB g)
                 frag_b(cur ^ 1, 0, 0, fb[0]);
             }
             mfmas(fa[ks & 1], fb[u & 1]);
+#ifdef KURBM_STAMPS
+            KURBM_STAMP(tq[u + 1]);
+            if (NPB == 3) tu[u] += tq[u + 1] - tq[u];
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -495,7 +505,8 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     const int nblk = g.grid_m * g.grid_n * g.nsplit;
 #define KURBM_PB(E, NZ)                                                                              \
     if (epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) {                                          \
-        hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, 3, E, NZ>), dim3(nblk), dim3(512), 0, st, g); \
+        if (g.cfg == 1) hipLaunchKernelGGL((k_gemm_pb<128, 64, 2, 2, 64, 3, E, NZ>), dim3(nblk), dim3(256), 0, st, g); \
+        else hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, 3, E, NZ>), dim3(nblk), dim3(512), 0, st, g); \
         return hipGetLastError();                                                                    \
     }
     KURBM_PB(EPI_HALFSTEP, NOISE_NONE)

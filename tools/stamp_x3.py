@@ -37,7 +37,8 @@ def report(name, s):
         ok = (a > 0) & (b > 0)
         d.append(np.median((b - a)[ok]) if ok.any() else 0.0)
     end = s[:, 5].max() - t0
-    print("%-10s wgs %4d | " % (name, len(s)) + "  ".join("%s %6.0f" % (n, x) for n, x in zip(NAMES[1:], d[1:])))
+    print("%-10s wgs %4d | " % (name, len(s)) + "  ".join("%s %6.0f" % (n, x) for n, x in zip(NAMES[1:], d[1:]))
+          + " | micro-steps u0..u5: " + " ".join("%6.0f" % x for x in np.median(s[:, 8:14], axis=0)))
 
 
 step = lambda: eng.cd_step(V, B, 0, 1e-3 / B, 42, 0, compute="x3")
@@ -52,4 +53,7 @@ lib.kurbm_debug_set_stamp_buffer(None)
 s = buf.cpu().numpy().astype(np.float64).reshape(4, 512, 8, 16)
 for n, name in enumerate(("vh sample", "hv sample", "vh prob", "statistics")):
     report(name, s[n, :, 0])
+    if n == 0:
+        for wv in (1, 4, 5):
+            report("  wave %d" % wv, s[n, :, wv])
 
