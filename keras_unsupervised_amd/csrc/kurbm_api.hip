@@ -513,9 +513,9 @@ void kurbm_debug_set_off(int mask) { set_debug_off(mask); }
 //   pieces = 3  "x3":   every fp32 operand carried EXACTLY as three bf16 pieces (hi + mid + lo), one
 //                       k-segment of the NT GEMM per pair of pieces; 0/1 samples are a single piece
 // ======================================================================================
-// Leading dimensions of every bf16 plane are the k extent plus one 128-byte line: a row stride that is a
-// multiple of 2 KiB (k = 1024, 4096 ...) would send a whole column of a tile to ONE L2 channel.
-static inline int ld_pad(int k) { return k + env_int("KURBM_LDPAD", 64); }
+// Leading dimension of a bf16 plane = its k extent (+ KURBM_LDPAD elements: an experiment knob.  Row strides
+// that are multiples of 2 KiB were suspected of camping on one L2 channel; padding them changed nothing.)
+static inline int ld_pad(int k) { return k + env_int("KURBM_LDPAD", 0); }
 
 struct Mirror { uint16_t *Wb, *Wtb; int Kh, Kv, ldW, ldWt, pieces; size_t planeW, planeWt, bytes; };
 

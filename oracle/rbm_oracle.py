@@ -72,6 +72,20 @@ def bf16_round(x):
     return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
 
 
+def bf16_split3(x):
+    """Exact three-way split of float32 values into bf16 pieces, x == hi + mid + lo (the x3 compute path:
+    include/kurbm.h, kurbm_device.h bf16_piece_bits).  Round to nearest even at each stage; both residuals
+    are exact in float32 and the last one has at most 8 significant bits, so the sum is exact.  The x3
+    kernels multiply the pieces on the bf16 matrix cores and accumulate in float32: their CPU statement
+    is the plain float32 oracle (cd_step_fused), not a reduced-precision one."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    hi = bf16_round(x)
+    r1 = x - hi
+    mid = bf16_round(r1)
+    lo = bf16_round(r1 - mid)
+    return hi, mid, lo
+
+
 def cd_step_fused_bf16(W, b_h, b_v, v_batch, lr, seed, step, k=1, row0=0, mode=MODE_VISIBLE_BERNOULLI, v_chain=None):
     """cd_step_fused with every matrix-product operand rounded to bf16 (weights, data, the h_neg
     probabilities; 0/1 samples are exact); biases, activations, sums and the update stay float32 and

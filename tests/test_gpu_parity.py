@@ -525,7 +525,8 @@ def test_random_shape_sweep(gpu_device):
         assert rel_err(dW, dW_ref) <= TOL and rel_err(dbh, dbh_ref) <= TOL and np.array_equal(dbv, dbv_ref), (case, B, nv, nh, k)
 
 
-def test_data_parallel_emulation_two_shards(gpu_device):
+@pytest.mark.parametrize("compute", ["fp32", "x3"])
+def test_data_parallel_emulation_two_shards(gpu_device, compute):
     """The N > 1 update sequence with the real kernels, two 'ranks' emulated on one GPU: each runs the
     chain on its shard (global-row Philox counters), the packed deltas are summed (the all-reduce) and
     applied on both replicas.  Replicas stay bit-identical and track the single-rank run within the fp32
@@ -540,12 +541,13 @@ def test_data_parallel_emulation_two_shards(gpu_device):
     lr = 0.01
     for step in range(2):
         lo = step * B
-        single.cd_step(vd, B, lo, lr, 21, step, k=2)
+        single.cd_step(vd, B, lo, lr, 21, step, k=2, compute=compute)
         deltas = []
         for r, e in enumerate(ranks):
             s_lo, s_hi = dp.shard_rows(B, 2, r)
             assert s_lo % 4 == 0
-            e.cd_step(vd, s_hi - s_lo, lo + s_lo, lr, 21, step, k=2, apply=False, emit_delta=True, row0=s_lo)
+            e.cd_step(vd, s_hi - s_lo, lo + s_lo, lr, 21, step, k=2, apply=False, emit_delta=True, row0=s_lo,
+                      compute=compute)
             deltas.append(e.delta_buffer().clone())
         total = deltas[0] + deltas[1]                      # what all_reduce(SUM) leaves on every rank
         for e in ranks:

@@ -159,3 +159,25 @@ def test_second_opinion_torch():
     # bf16 rounding helper against torch's own conversion
     x = np.linspace(-3, 3, 1001, dtype=np.float32) * np.float32(1.2345)
     assert np.array_equal(O.bf16_round(x), torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy())
+
+
+def test_bf16_split3_is_exact():
+    """x == hi + mid + lo in float32 for every finite float32, each piece a bf16 value (x3 path)."""
+    g = np.random.default_rng(7)
+    x = np.concatenate([
+        g.standard_normal(200000).astype(np.float32) * np.float32(0.05),
+        g.random(200000).astype(np.float32),                              # probabilities
+        (g.standard_normal(1000) * 1e-30).astype(np.float32), (g.standard_normal(1000) * 1e30).astype(np.float32),
+        np.array([0.0, -0.0, 1.0, -1.0, 0.1, 1.0 - 2.0 ** -24, 2.0 ** -126, 3.0 * 2.0 ** -126, np.float32(1) / 3], np.float32),
+        np.frombuffer(g.bytes(4 * 100000), dtype=np.uint32).astype(np.uint32).view(np.float32),
+    ])
+    x = x[np.isfinite(x) & (np.abs(x) < 3e38)]
+    x = x[(np.abs(x) >= 2.0 ** -100) | (x == 0)]          # pieces of values this small underflow bf16's own range
+    hi, mid, lo = O.bf16_split3(x)
+    for p in (hi, mid, lo):
+        assert np.array_equal(p, O.bf16_round(p)), "a piece must be exactly a bf16 value"
+    assert np.array_equal((hi + mid) + lo, x) and np.array_equal(hi.astype(np.float64) + mid + lo, x.astype(np.float64))
+    # 0/1 samples are a single piece
+    s = (g.random(1000) < 0.3).astype(np.float32)
+    hi, mid, lo = O.bf16_split3(s)
+    assert np.array_equal(hi, s) and not mid.any() and not lo.any()
