@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of the x3 kernels from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; collected
+separately, as MI355X_MICROARCH.md prescribes):  pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def load(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void kurbm::", "").replace("kurbm::", "")
+        wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+        acc[(name, wgs)].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+label = {("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 1>", 256): "x3_half_step_vh_sample",
+         ("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 1>", 224): "x3_half_step_hv_sample",
+         ("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 0>", 256): "x3_half_step_vh_prob",
+         ("k_gemm_pb<128, 128, 2, 4, 64, 3, 1, 0>", 224): "x3_stats_gemm"}
+out = {}
+for key in sorted(set(fetch) | set(write)):
+    name = label.get(key)
+    if name is None and "reduce_apply" in key[0]:
+        name = "x3_reduce_apply"
+    if name is None and "f32_to_bf16" in key[0]:
+        name = "x3_f32_to_bf16_wgs%d" % key[1]
+    if name is None:
+        continue
+    f, w = fetch.get(key, 0.0), write.get(key, 0.0)
+    out[name] = {"rocprof_kernel": key[0], "workgroups": key[1], "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+                 "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+                 "note": "FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request on wide coalesced reads, "
+                         "MI355X_MICROARCH.md HBM section); WRITE_SIZE as read"}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in out.items()}))
