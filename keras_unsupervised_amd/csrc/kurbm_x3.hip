@@ -177,17 +177,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
     struct Regs { u32x4 a[NA], b[PB][NB1]; };
     Regs r0, r1;   // two tiles in flight between global memory and LDS (fetched two tiles ahead)
     // branch-free: a piece the segment does not use is fetched from the last one it does (same lines)
-    auto fetch = [&](Regs& R, const TileRef& r) {
+    // part 0 = the A chunks, part 1 + p = piece p of B.  The L1 path takes ~16 cycles per 1-KiB wave load (64 B/clk per
+    // CU): the eight loads of a tile issued back to back by all eight waves stall the later waves for ~1000 cycles,
+    // so the k loop issues one part per micro-step.
+    auto fetch_part = [&](Regs& R, const TileRef& r, int part) {
+        if (part == 0) {
 #pragma unroll
-        for (int it = 0; it < NA; ++it)
-            R.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA, goffA[it], r.oa, 0));
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
+            for (int it = 0; it < NA; ++it)
+                R.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA, goffA[it], r.oa, 0));
+        } else {
+            const int p = part - 1;
             const uint32_t so = __builtin_amdgcn_readfirstlane(r.ob + (uint32_t)(p < r.npb ? p : r.npb - 1) * r.bplane);
 #pragma unroll
             for (int it = 0; it < NB1; ++it)
                 R.b[p][it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dB, goffB[it], so, 0));
         }
+    };
+    auto fetch = [&](Regs& R, const TileRef& r) {
+#pragma unroll
+        for (int part = 0; part <= PB; ++part) fetch_part(R, r, part);
     };
     // park chunks [c0, c1) of the tile held in R: chunk order = A, piece 0 of B, piece 1, ...
     constexpr int NCH = NA + PB * NB1;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 fa[2][TM], fb[2][TN];   // fragment double buffers: A by k-step, B by micro-step
+    u32x4 fa[2][TM], fb[3][TN];   // fragment buffers: A by k-step; B by micro-step (three: read two steps ahead)
     // fragment rows are l15 + a multiple of 16, so their swizzle key is (l15 >> 1) & 7
     const int swz = (l15 >> 1) & 7;
     auto frag_a = [&](int buf, int ks, u32x4 (&f)[TM]) {
@@ -251,7 +259,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             __builtin_amdgcn_sched_barrier(0);
-            if (u == 0) fetch(L, r2);
+            if constexpr (NU > PB) {   // one part of tile i+2 per micro-step
+                if (u <= PB) fetch_part(L, r2, u);
+            } else {
+                if (u == 0) fetch(L, r2);
+            }
             if constexpr (NU >= 4) {   // parks spread over the middle micro-steps
                 constexpr int NMID = NU - 2;
                 if (u >= 1 && u <= NMID) park(P, cur ^ 1, rp, (u - 1) * NCH / NMID, u * NCH / NMID);
@@ -259,6 +271,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
                 if (u == 0) park(P, cur ^ 1, rp, 0, NCH);
             }
             const int ks = u / NPB;
+            if constexpr (NPB == 3) {
+                // fragments are read TWO micro-steps ahead (an LDS read under load takes longer than the 8 MFMAs
+                // of one micro-step); the tile is entered with fa[0], fb[0] loaded, so u = 0 catches up
+                if (u == 0) { frag_b(cur, 0, 1, fb[1]); frag_b(cur, 0, 2, fb[2]); }
+                if (u == 1) { frag_a(cur, 1, fa[1]); frag_b(cur, 1, 0, fb[0]); }
+                if (u == 2) frag_b(cur, 1, 1, fb[1]);
+                if (u == 3) frag_b(cur, 1, 2, fb[2]);
+                if (u == NU - 1) {
+                    __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                    frag_a(cur ^ 1, 0, fa[0]);
+                    frag_b(cur ^ 1, 0, 0, fb[0]);
+                }
+                mfmas(fa[ks & 1], fb[u % 3]);
+#ifdef KURBM_STAMPS
+                KURBM_STAMP(tq[u + 1]);
+                tu[u] += tq[u + 1] - tq[u];
+#endif
+                continue;
+            }
             if (u + 1 < NU) {
                 const int ksn = (u + 1) / NPB, pn = (u + 1) % NPB;
                 if (pn == 0) frag_a(cur, ksn, fa[ksn & 1]);
