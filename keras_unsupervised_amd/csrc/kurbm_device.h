@@ -46,8 +46,15 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+// two floats -> packed bf16 pair, round to nearest even: ONE gfx950 instruction (no builtin for it in ROCm 7.2)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// neighbouring lane of the pair (lane ^ 1) by DPP quad_perm [1,0,3,2]: no LDS crossbar round trip
+__device__ __forceinline__ float pair_swap(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
 }
 
 

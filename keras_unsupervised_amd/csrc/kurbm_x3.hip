@@ -315,11 +315,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
         else one_tile(cur, L, P, rp, r2, std::integral_constant<int, 1>{});
     };
 
+    // The Philox words of this lane's outputs do not depend on the GEMM: they are drawn while the first two
+    // tiles are on their way from memory (the vector ALU is idle then), not in the epilogue.
+    uint32_t draws[(NOISE != NOISE_NONE) ? TM * TN : 1][4];
+    auto draw_all = [&]() {
+        if (NOISE == NOISE_NONE) return;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const uint64_t grow = g.rng.row0 + (uint64_t)(m0 + wm * WM + slot * 4 + mi * 16);
+                uint32_t (&w)[4] = draws[(NOISE != NOISE_NONE) ? ni * TM + mi : 0];
+                philox4x32_10((uint32_t)(n0 + wn * WN + l15 + ni * 16), (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step,
+                              g.rng.seed_lo, g.rng.seed_hi, w);
+                asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));   // drawn HERE, not sunk into the epilogue
+            }
+    };
+    float biasv[TN];   // loaded here too: in the epilogue its latency would be exposed
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int c = n0 + wn * WN + l15 + ni * 16;
+        biasv[ni] = (EPI == EPI_HALFSTEP && c < g.N) ? g.bias[c] : 0.f;
+    }
     if (nt > 0) {
         TileRef rc = tile_of(t_begin), rn = tile_of(t_begin + 1);
         fetch(r0, rc);
-        park(r0, 0, rc, 0, NCH);
         fetch(r1, rn);
+        draw_all();
+        park(r0, 0, rc, 0, NCH);
         __syncthreads();
         frag_a(0, 0, fa[0]);
         frag_b(0, 0, 0, fb[0]);
@@ -383,16 +406,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
             for (int ni = 0; ni < TN; ++ni) {
                 const int col = colb + ni * 16;
                 const bool col_ok = col < g.N;
-                const float bias = col_ok ? g.bias[col] : 0.f;
+                const float bias = biasv[ni];
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi) {
                     const int rowb = rowq + mi * 16;
-                    uint32_t w[4] = {0u, 0u, 0u, 0u};
-                    if (NOISE != NOISE_NONE) {
-                        const uint64_t grow = g.rng.row0 + (uint64_t)rowb;
-                        philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step, g.rng.seed_lo,
-                                      g.rng.seed_hi, w);
-                    }
+                    const uint32_t (&w)[4] = draws[(NOISE != NOISE_NONE) ? ni * TM + mi : 0];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x = acc[mi][ni][r] + bias;
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
                         if (ACT == ACT_SIGMOID) p = sigmoidf_fast(x);
                         else if (ACT == ACT_RELU) p = fmaxf(x, 0.f);
                         else p = x;
-                        const float ua = u32_to_unit(w[r]);
+                        const float ua = (NOISE != NOISE_NONE) ? u32_to_unit(w[r]) : 0.f;
                         xv[mi][ni][r] = (NOISE == NOISE_BERNOULLI) ? ((ua < p) ? 1.0f : 0.0f) : p;
                         if (NOISE != NOISE_NONE && g.side && col_ok && rowb + r < g.M) {   // test planes
                             if (g.prob_f32) g.prob_f32[(size_t)(rowb + r) * g.ldo32 + col] = p;
@@ -433,6 +451,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
         }
     }
 
+#ifdef KURBM_STAMPS
+    unsigned long long te[5] = {0, 0, 0, 0, 0};
+    KURBM_STAMP(te[0]);
+#endif
     // (b) transposed bf16 plane(s) [N][ldoT]: 4 consecutive rows of this lane's column = one 8-byte store;
     //     rows past M (k padding of the statistics GEMM) are written as zeros
     if (g.outT) {
@@ -462,6 +484,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
         }
     }
 
+#ifdef KURBM_STAMPS
+    KURBM_STAMP(te[1]);
+#endif
     // (c) fp32 copy of the value plane (persistent chain, test hooks): 16 lanes x 4 B per row
     if (g.out_f32) {
 #pragma unroll
@@ -489,13 +514,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
                 for (int h = 0; h < 2; ++h) {
                     const float mine = col_ok ? (odd ? xv[mi][ni][2 * h + 1] : xv[mi][ni][2 * h]) : 0.f;
                     const float send = col_ok ? (odd ? xv[mi][ni][2 * h] : xv[mi][ni][2 * h + 1]) : 0.f;
-                    const float recv = __shfl_xor(send, 1);
+                    const float recv = pair_swap(send);
                     const uint32_t pk = odd ? pack_bf16x2(recv, mine) : pack_bf16x2(mine, recv);
                     *reinterpret_cast<uint32_t*>(smem + (wm * WM + mi * 16 + slot * 4 + 2 * h + odd) * PROW16 +
                                                  2 * (wn * WN + ni * 16 + (l15 & ~1))) = pk;
                 }
         }
+#ifdef KURBM_STAMPS
+        KURBM_STAMP(te[2]);
+#endif
         __syncthreads();
+#ifdef KURBM_STAMPS
+        KURBM_STAMP(te[3]);
+#endif
         constexpr int CH = BN / 8;   // 16-B chunks per row
 #pragma unroll
         for (int j = 0; j < BM * CH / NT; ++j) {
@@ -507,6 +538,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
         }
     }
     KURBM_STAMP(ts[4]);
+#ifdef KURBM_STAMPS
+    tu[0] = te[0] - ts[3]; tu[1] = te[1] - te[0]; tu[2] = te[2] ? te[2] - te[1] : 0; tu[3] = te[3] ? te[3] - te[2] : 0;
+    tu[4] = te[3] ? ts[4] - te[3] : ts[4] - te[1]; tu[5] = 0;
+#endif
     KURBM_STAMP_OUT();
 }
 
