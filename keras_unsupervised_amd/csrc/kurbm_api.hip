@@ -604,10 +604,10 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.hnT = take16(pieces * w.planeHT);                                              // h_neg probabilities, transposed
     w.cb = take16(v_pieces * w.planeV);                                              // persistent chain as bf16
     // bias partials.  bf16: one row per row tile.  x3: hidden = rows of +sum(h_pos) then rows of -sum(h_neg);
-    // visible = one row per 32-row band of v_pos (conversion kernel) then rows of -sum(v_neg)
+    // visible = one row per 64-row band of v_pos (conversion kernel) then rows of -sum(v_neg)
     // (k_gemm_pb writes one row per 64-row half of a 128-row tile: two rows per tile)
     w.part_h = take32((size_t)4 * w.max_row_tiles * w.ldh32);
-    w.part_v = take32((size_t)(ceil_div(rows, 32) + 2 * w.max_row_tiles) * w.ldv32);
+    w.part_v = take32((size_t)(ceil_div(rows, 64) + 2 * w.max_row_tiles) * w.ldv32);
     w.slab = take32(w.slab_stride * pl.nsplit_bound);
     w.tmp32 = take32((size_t)rows * (w.ldh32 > w.ldv32 ? w.ldh32 : w.ldv32));       // fp32 plane for the test hook
     w.bytes = off;
@@ -780,9 +780,9 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     int e;
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
-    // (x3: plus the column sums of v_pos per 32-row band, the positive half of the visible-bias statistics)
+    // (x3: plus the column sums of v_pos per 64-row band, the positive half of the visible-bias statistics)
     const bool pb = (pieces == 3) && !env_int("KURBM_X3_SEGMENTS", 0);
-    const int gp_v = pb ? ceil_div(rows, 32) : 0;
+    const int gp_v = pb ? ceil_div(rows, 64) : 0;
     if (KURBM_STAGE(0))
         HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Lv, w.Kb, w.vbT, w.Lb, p->n_vis, v_pieces, w.planeV,
                                    w.planeVT, pb ? w.part_v : nullptr, w.ldv32, st));

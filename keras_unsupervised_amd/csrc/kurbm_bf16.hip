@@ -34,52 +34,67 @@ constexpr int NTH = 256;
 // ------------------------------------------------------------------------------------
 // fp32 [rows][ld_in] -> bf16 [rows_pad][ldo] (+ transposed bf16 [cols_pad][ldoT]); padding zeroed
 // ------------------------------------------------------------------------------------
-// One 32 x 32 tile per workgroup through LDS; out-of-range source elements read as zero, so the
-// k padding of both mirrors is written here and nowhere else.
-// pieces = 3 writes the exact split x = hi + mid + lo (bf16_piece_bits) as three planes.
+// One TR x 64 tile per workgroup through LDS (TR = 64, or 16 when the matrix is too small to fill the chip with
+// 64-row tiles): 16-byte loads, 8-byte stores in both orientations.
+// Out-of-range source elements read as zero, so the k padding of both mirrors is written here and
+// nowhere else.  pieces = 3 writes the exact split x = hi + mid + lo (bf16_piece_bits) as three planes.
+// colpart (nullable): column sums of each 64-row band of `in`.
+constexpr int CVT = 64;
+template <int TR>
 __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ in, int rows, int cols, int ld_in,
                                                      uint16_t* __restrict__ out, int ldo, int out_rows,
                                                      uint16_t* __restrict__ outT, int ldoT, int outT_rows,
                                                      int pieces, size_t out_plane, size_t outT_plane,
                                                      float* __restrict__ colpart, int ld_colpart) {
-    __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = r0 + ty + 8 * j, c = c0 + tx;
-        const float v = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : 0.f;
-        tile[ty + 8 * j][tx] = v;
-        if (out && r < out_rows && c < ldo) {
-            const size_t o = (size_t)r * ldo + c;
-            out[o] = (uint16_t)bf16_piece_bits(v, 0);
-            if (pieces == 3) {
-                out[o + out_plane] = (uint16_t)bf16_piece_bits(v, 1);
-                out[o + 2 * out_plane] = (uint16_t)bf16_piece_bits(v, 2);
+    __shared__ float tile[TR][CVT + 1];
+    const int t = threadIdx.x;
+    const int q4 = (t & 15) * 4, rq = t >> 4;           // 16 lanes x 4 elements across, 16 rows per pass
+    const int r0 = blockIdx.y * TR, c0 = blockIdx.x * CVT;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    auto store3 = [&](uint16_t* dst, size_t plane, float a, float b, float c, float d) {
+        float v[4] = {a, b, c, d};
+        for (int j = 0; j < pieces; ++j) {
+            u32x2 pk;
+            pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(dst + j * plane) = pk;
+            if (j + 1 < pieces) {   // residual of the piece just written: exact in fp32
+                v[0] -= bf16_bits_to_f32(pk.x & 0xFFFFu); v[1] -= bf16_bits_to_f32(pk.x >> 16);
+                v[2] -= bf16_bits_to_f32(pk.y & 0xFFFFu); v[3] -= bf16_bits_to_f32(pk.y >> 16);
             }
         }
+    };
+#pragma unroll
+    for (int j = 0; j < TR / 16; ++j) {
+        const int r = r0 + rq + 16 * j, c = c0 + q4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows && c < cols) {      // ld_in % 4 == 0 and c % 4 == 0: the 16-byte load stays inside the row
+            v = *reinterpret_cast<const f32x4*>(in + (size_t)r * ld_in + c);
+            if (c + 1 >= cols) v.y = 0.f;
+            if (c + 2 >= cols) v.z = 0.f;
+            if (c + 3 >= cols) v.w = 0.f;
+        }
+        tile[rq + 16 * j][q4 + 0] = v.x; tile[rq + 16 * j][q4 + 1] = v.y;
+        tile[rq + 16 * j][q4 + 2] = v.z; tile[rq + 16 * j][q4 + 3] = v.w;
+        if (out && r < out_rows && c < ldo) store3(out + (size_t)r * ldo + c, out_plane, v.x, v.y, v.z, v.w);   // ldo % 8 == 0
     }
     if (!outT && !colpart) return;
     __syncthreads();
-    if (colpart && ty == 0 && r0 < rows && c0 + tx < cols) {   // out-of-range elements were staged as zeros
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) t += tile[i][tx];
-        colpart[(size_t)blockIdx.y * ld_colpart + c0 + tx] = t;
+    if (colpart && t < CVT && r0 < rows && c0 + t < cols) {   // out-of-range elements were staged as zeros
+        float s = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < TR; ++i) s += tile[i][t];
+        colpart[(size_t)blockIdx.y * ld_colpart + c0 + t] = s;
     }
     if (!outT) return;
+    // TR / 4 lanes x 4 rows across a column of the tile, 1024 / TR columns per pass
+    constexpr int LPC = TR / 4, CPP = 256 / LPC;
+    const int rr4 = (t % LPC) * 4, cq = t / LPC;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = c0 + ty + 8 * j, r = r0 + tx;   // outT[c][r]
-        if (c < outT_rows && r < ldoT) {
-            const float v = tile[tx][ty + 8 * j];
-            const size_t o = (size_t)c * ldoT + r;
-            outT[o] = (uint16_t)bf16_piece_bits(v, 0);
-            if (pieces == 3) {
-                outT[o + outT_plane] = (uint16_t)bf16_piece_bits(v, 1);
-                outT[o + 2 * outT_plane] = (uint16_t)bf16_piece_bits(v, 2);
-            }
-        }
+    for (int j = 0; j < CVT / CPP; ++j) {
+        const int c = c0 + cq + CPP * j, r = r0 + rr4;    // outT[c][r .. r+3]
+        if (c < outT_rows && r < ldoT)                    // ldoT % 8 == 0
+            store3(outT + (size_t)c * ldoT + r, outT_plane, tile[rr4 + 0][cq + CPP * j], tile[rr4 + 1][cq + CPP * j],
+                   tile[rr4 + 2][cq + CPP * j], tile[rr4 + 3][cq + CPP * j]);
     }
 }
 
@@ -522,9 +537,17 @@ hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, ui
     int r_ext = rows, c_ext = cols;
     if (out) { if (out_rows > r_ext) r_ext = out_rows; if (ldo > c_ext) c_ext = ldo; }
     if (outT) { if (ldoT > r_ext) r_ext = ldoT; if (outT_rows > c_ext) c_ext = outT_rows; }
-    dim3 grid((c_ext + 31) / 32, (r_ext + 31) / 32);
-    hipLaunchKernelGGL(k_f32_to_bf16, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
-                       outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart);
+    // colpart bands are 64 rows, so a launch that wants them keeps 64-row tiles
+    const bool small = !colpart && ((c_ext + CVT - 1) / CVT) * ((r_ext + CVT - 1) / CVT) < 512;
+    if (small) {
+        dim3 grid((c_ext + CVT - 1) / CVT, (r_ext + 15) / 16);
+        hipLaunchKernelGGL(k_f32_to_bf16<16>, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
+                           outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart);
+    } else {
+        dim3 grid((c_ext + CVT - 1) / CVT, (r_ext + CVT - 1) / CVT);
+        hipLaunchKernelGGL(k_f32_to_bf16<64>, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
+                           outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart);
+    }
     return hipGetLastError();
 }
 

@@ -169,7 +169,7 @@ void tile_shape(int cfg, int* bm, int* bn);
 hipError_t launch_gemm_bf16(int epi, const GemmArgsB& g, hipStream_t st);
 hipError_t launch_gemm_pb(int epi, const GemmArgsB& g, hipStream_t st);
 // pieces = 1: round to nearest bf16; 3: exact split x = hi + mid + lo, piece j at out + j * out_plane
-// colpart (nullable): [ceil(rows / 32)][ld_colpart] column sums of each 32-row band of `in`
+// colpart (nullable): [ceil(rows / 64)][ld_colpart] column sums of each 64-row band of `in`
 hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
                               uint16_t* outT, int ldoT, int outT_rows, int pieces, size_t out_plane, size_t outT_plane,
                               float* colpart, int ld_colpart, hipStream_t st);
