@@ -125,7 +125,7 @@ def main():
         else:
             eng.cd_step(V, BATCH, lo, lr, seed, i, apply=False, emit_delta=True, row0=rank * BATCH, compute=args.compute)
             dp.allreduce_sum_(eng.delta_buffer())
-            eng.apply_delta(lr)
+            eng.apply_delta(lr, compute=args.compute)
 
     for i in range(args.warmup):
         step(i)

@@ -257,6 +257,11 @@ int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, 
                            int which, int stage, void* workspace, size_t workspace_bytes,
                            kurbm_stream_t stream);
 
+/* kurbm_apply_delta for the x3 path (data-parallel step): W, b_h, b_v += lr * delta AND the mirror's weight
+ * pieces rewritten, in one launch. */
+int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                         const float* delta, float lr, int which, kurbm_stream_t stream);
+
 /* One half step on the x3 path (transform / test hook): dir 0 = v->h, 1 = h->v. */
 int kurbm_half_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, int dir,
                        const float* in, int in_pieces, int rows, int ld_in, int act, int noise,

@@ -890,10 +890,20 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     a.part_v = w.part_v; a.nrow_tiles_v = pb ? gp_v + 2 * gm_v : gm_v; a.ld_part_v = w.ldv32;
     a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
     a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
-    if (KURBM_STAGE(5)) HIP_TRY(launch_reduce_apply(a, st));
-    if (a.W && (KURBM_STAGE(5) || only == 6))   // the fp32 master moved: re-derive both mirrors
-        HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, pieces,
-                                   m.planeW, m.planeWt, nullptr, 0, st));
+    if (a.W && need_w && !env_int("KURBM_UNFUSED_MIRROR", 0)) {
+        // the fp32 master moves: the slab reduction writes the new weights AND their bf16 pieces in one launch
+        a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
+        a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = pieces;
+        if (KURBM_STAGE(5)) HIP_TRY(launch_reduce_apply_split(a, st));
+        if (only == 6)
+            HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, pieces,
+                                       m.planeW, m.planeWt, nullptr, 0, st));
+    } else {
+        if (KURBM_STAGE(5)) HIP_TRY(launch_reduce_apply(a, st));
+        if (a.W && (KURBM_STAGE(5) || only == 6))   // the fp32 master moved: re-derive both mirrors
+            HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, pieces,
+                                       m.planeW, m.planeWt, nullptr, 0, st));
+    }
 #undef KURBM_STAGE
     return KURBM_OK;
 }
@@ -959,6 +969,36 @@ int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, 
     if (stage < 0 || stage > 6) return fail(KURBM_ERR_ARG, "stage must be in [0, 6]");
     return cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, which, workspace, workspace_bytes, stream,
                        stage);
+}
+
+int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* delta,
+                         float lr, int which, kurbm_stream_t stream) {
+    if (!ctx || !delta) return fail(KURBM_ERR_ARG, "null argument");
+    if (int e = check_params(p)) return e;
+    if (!mirror || !aligned16(mirror) || !aligned16(delta)) return fail(KURBM_ERR_ARG, "mirror / delta null or misaligned");
+    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, 3);
+    if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((p->n_hid & 3) || !(which & 1)) {   // packed rows not 16-byte aligned, or W untouched: two launches
+        if (int e = kurbm_apply_delta(ctx, p, delta, lr, which, stream)) return e;
+        if (which & 1)
+            HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, 3,
+                                       m.planeW, m.planeWt, nullptr, 0, st));
+        return KURBM_OK;
+    }
+    // the packed delta is one "slab" and one row of bias partials each: W += lr * dW, pieces rewritten, one launch
+    ReduceArgs a;
+    memset(&a, 0, sizeof a);
+    const size_t nw = (size_t)p->n_vis * p->n_hid;
+    a.slab = delta; a.slab_stride = 0; a.nslab = 1; a.ld_slab = p->n_hid;
+    a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw; a.lr = lr;
+    a.W = p->W;
+    a.part_h = delta + nw; a.nrow_tiles_h = 1; a.ld_part_h = p->n_hid; a.b_h = (which & 2) ? p->b_h : nullptr;
+    a.part_v = delta + nw + p->n_hid; a.nrow_tiles_v = 1; a.ld_part_v = p->n_vis; a.b_v = (which & 4) ? p->b_v : nullptr;
+    a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
+    a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = 3;
+    HIP_TRY(launch_reduce_apply_split(a, st));
+    return KURBM_OK;
 }
 
 int kurbm_bf16_exact(kurbm_ctx* ctx, const float* x, int rows, int cols, int ld, int* flag, kurbm_stream_t stream) {

@@ -98,6 +98,105 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
     }
 }
 
+// ------------------------------------------------------------------------------------
+// slab reduction + parameter update + weight-piece mirror in ONE launch (x3 / bf16 steps)
+// ------------------------------------------------------------------------------------
+// Blocks [0, tiles): a 16 x 64 tile of W each -- sum the split-K slabs in index order (bit-reproducible), W += lr * dW
+// (and / or emit dW), then write the NEW weights as bf16 pieces row-major (8-byte stores) and, through an LDS transpose,
+// transposed; the k padding of both mirrors is rewritten as zeros.  Remaining blocks: the bias column sums of
+// k_reduce_apply (kurbm_kernels.hip).  Replaces k_reduce_apply + k_f32_to_bf16 on the fp32 master (one launch, one
+// pass over W instead of three).
+__global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int tiles_x, int tiles) {
+    constexpr int TR = 16;
+    __shared__ float tile[TR][CVT + 1];
+    const int t = threadIdx.x;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    if ((int)blockIdx.x < tiles) {
+        const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+        const int q4 = (t & 15) * 4, rq = t >> 4;
+        const int r = by * TR + rq, c = bx * CVT + q4;
+        auto store3 = [&](uint16_t* dst, size_t plane, float v0, float v1, float v2, float v3) {
+            float v[4] = {v0, v1, v2, v3};
+            for (int j = 0; j < a.pieces; ++j) {
+                u32x2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<u32x2*>(dst + j * plane) = pk;
+                if (j + 1 < a.pieces) {
+                    v[0] -= bf16_bits_to_f32(pk.x & 0xFFFFu); v[1] -= bf16_bits_to_f32(pk.x >> 16);
+                    v[2] -= bf16_bits_to_f32(pk.y & 0xFFFFu); v[3] -= bf16_bits_to_f32(pk.y >> 16);
+                }
+            }
+        };
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (r < a.n_vis && c < a.n_hid) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (a.slab) {
+                const float* sp = a.slab + (size_t)r * a.ld_slab + c;    // ld_slab % 4 == 0: the group stays inside the row
+                int zz = 0;
+                for (; zz + 4 <= a.nslab; zz += 4) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 0) * a.slab_stride);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 1) * a.slab_stride);
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 2) * a.slab_stride);
+                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 3) * a.slab_stride);
+                    s += v0; s += v1; s += v2; s += v3;
+                }
+                for (; zz < a.nslab; ++zz) s += *reinterpret_cast<const f32x4*>(sp + (size_t)zz * a.slab_stride);
+            }
+            if (a.W) {
+                float* wp = a.W + (size_t)r * a.ldw + c;                  // ldw % 4 == 0
+                w = *reinterpret_cast<const f32x4*>(wp);
+                if (a.slab) w = w + s * a.lr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e >= a.n_hid) w[e] = 0.f;                     // the row padding stays zero
+                if (a.slab) *reinterpret_cast<f32x4*>(wp) = w;
+            }
+            if (a.delta_w) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < a.n_hid) a.delta_w[(size_t)r * a.n_hid + c + e] = s[e];
+            }
+        }
+        tile[rq][q4 + 0] = w.x; tile[rq][q4 + 1] = w.y; tile[rq][q4 + 2] = w.z; tile[rq][q4 + 3] = w.w;
+        if (a.Wb && r < a.n_vis && c < a.ldWb) store3(a.Wb + (size_t)r * a.ldWb + c, a.planeWb, w.x, w.y, w.z, w.w);
+        __syncthreads();
+        if (a.Wtb) {
+            const int rr4 = (t & 3) * 4, cq = t >> 2;       // 4 lanes x 4 rows down a column, 64 columns
+            const int cc = bx * CVT + cq, rr = by * TR + rr4;
+            if (cc < a.n_hid && rr < a.ldWtb)
+                store3(a.Wtb + (size_t)cc * a.ldWtb + rr, a.planeWtb, tile[rr4 + 0][cq], tile[rr4 + 1][cq], tile[rr4 + 2][cq],
+                       tile[rr4 + 3][cq]);
+        }
+        return;
+    }
+    // bias partials [row tiles][columns] -> column sums: eight loads in flight per lane, fixed order
+    const int q = ((int)blockIdx.x - tiles) * 256 + t;
+    auto colsum = [](const float* __restrict__ part, int ntiles, int ld, int col) {
+        float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int i = 0;
+        for (; i + 8 <= ntiles; i += 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] += part[(size_t)(i + e) * ld + col];
+        }
+        for (; i < ntiles; ++i) u[0] += part[(size_t)i * ld + col];
+        return ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+    };
+    if (q < a.n_hid) {
+        if (a.part_h) {
+            const float v = colsum(a.part_h, a.nrow_tiles_h, a.ld_part_h, q);
+            if (a.delta_bh) a.delta_bh[q] = v;
+            if (a.b_h) a.b_h[q] += a.lr * v;
+        }
+    } else if (q < a.n_hid + a.n_vis) {
+        const int col = q - a.n_hid;
+        if (a.part_v) {
+            const float v = colsum(a.part_v, a.nrow_tiles_v, a.ld_part_v, col);
+            if (a.delta_bv) a.delta_bv[col] = v;
+            if (a.b_v) a.b_v[col] += a.lr * v;
+        }
+    }
+}
+
 // flag := 1 if some element of `in` is not exactly representable in bf16 (the caller zeroes it)
 __global__ __launch_bounds__(256) void k_bf16_exact_check(const float* __restrict__ in, int rows, int cols, int ld_in,
                                                           int* __restrict__ flag) {
@@ -548,6 +647,17 @@ hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, ui
         hipLaunchKernelGGL(k_f32_to_bf16<64>, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
                            outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st) {
+    // the tile grid covers the padded extents of both mirrors (their zero k padding is written here)
+    int r_ext = a.n_vis, c_ext = a.n_hid;
+    if (a.Wb && a.ldWb > c_ext) c_ext = a.ldWb;
+    if (a.Wtb && a.ldWtb > r_ext) r_ext = a.ldWtb;
+    const int tiles_x = (c_ext + CVT - 1) / CVT, tiles_y = (r_ext + 15) / 16;
+    const int nb = (a.n_hid + a.n_vis + 255) / 256;
+    hipLaunchKernelGGL(k_reduce_apply_split, dim3(tiles_x * tiles_y + nb), dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y);
     return hipGetLastError();
 }
 

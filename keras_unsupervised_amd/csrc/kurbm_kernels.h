@@ -83,6 +83,11 @@ struct ReduceArgs {
     int nrow_tiles_v, ld_part_v;
     float* b_v;
     float* delta_bv;
+    // k_reduce_apply_split (kurbm_bf16.hip): the updated weights also leave as bf16 pieces, both orientations
+    uint16_t* Wb;         // [pieces][n_vis][ldWb]   nullable
+    uint16_t* Wtb;        // [pieces][n_hid][ldWtb]
+    int ldWb, ldWtb, pieces;
+    size_t planeWb, planeWtb;
 };
 
 struct ApplyArgs {
@@ -177,6 +182,7 @@ hipError_t launch_bf16_exact_check(const float* in, int rows, int cols, int ld_i
 hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g, hipStream_t st);
 hipError_t launch_philox_uniform(float* out, int rows, int cols, int ld, const RngArgs& rng, hipStream_t st);
 hipError_t launch_reduce_apply(const ReduceArgs& a, hipStream_t st);
+hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st);
 hipError_t launch_apply_delta(const ApplyArgs& a, hipStream_t st);
 hipError_t launch_free_energy_finish(const FinishArgs& a, hipStream_t st);
 

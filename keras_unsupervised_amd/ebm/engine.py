@@ -300,9 +300,18 @@ class DeviceRBM:
                                                     x.ptr(), rows, x.ld, *tail))
         return out
 
-    def apply_delta(self, lr, which=WHICH_ALL, delta=None):
+    def apply_delta(self, lr, which=WHICH_ALL, delta=None, compute=None):
+        """W, b_h, b_v += lr * delta (the all-reduced packed sums).  compute='x3' also rewrites the weight-piece
+        mirror in the same launch."""
         delta = self.delta_buffer() if delta is None else delta
         with torch.cuda.device(self.device):
+            if compute == "x3" and 3 in self._mirrors:
+                mir = self._mirrors[3][0]
+                check(self.lib.kurbm_x3_apply_delta(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                                    delta.data_ptr(), float(lr), int(which), self._stream()))
+                self._weights_written(kept=3)
+                self._mirrors[3][1] = False
+                return
             check(self.lib.kurbm_apply_delta(self.ctx.handle, C.byref(self.params), delta.data_ptr(), float(lr),
                                              int(which), self._stream()))
         self._weights_written()

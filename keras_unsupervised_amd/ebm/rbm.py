@@ -305,7 +305,7 @@ class RBM(object):
         else:
             delta.zero_()
         dp.allreduce_sum_(delta)
-        d.apply_delta(lr)
+        d.apply_delta(lr, compute=self._compute())
 
     # ------------------------------------------------------------------ config ----------
     def get_config(self):

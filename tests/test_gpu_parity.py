@@ -551,7 +551,7 @@ def test_data_parallel_emulation_two_shards(gpu_device, compute):
             deltas.append(e.delta_buffer().clone())
         total = deltas[0] + deltas[1]                      # what all_reduce(SUM) leaves on every rank
         for e in ranks:
-            e.apply_delta(lr, delta=total)
+            e.apply_delta(lr, delta=total, compute=compute)
     torch.cuda.synchronize()
     a, b, ref = ranks[0].get_weights(), ranks[1].get_weights(), single.get_weights()
     for x, y, z in zip(a, b, ref):
