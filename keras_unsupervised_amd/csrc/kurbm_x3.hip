@@ -315,20 +315,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
         else one_tile(cur, L, P, rp, r2, std::integral_constant<int, 1>{});
     };
 
-    // The Philox words of this lane's outputs do not depend on the GEMM: they are drawn while the first two
-    // tiles are on their way from memory (the vector ALU is idle then), not in the epilogue.
+    // The Philox words of this lane's outputs do not depend on the GEMM.  Those of its first DRAW_EARLY output
+    // columns are drawn while the first two tiles are on their way from memory (the vector ALU is idle then; more
+    // calls than that wait would cover only lengthen the prologue), the rest in the epilogue.
+    constexpr int DRAW_EARLY = (TN + 1) / 2;
     uint32_t draws[(NOISE != NOISE_NONE) ? TM * TN : 1][4];
-    auto draw_all = [&]() {
+    auto draw_cols = [&](int ni0, int ni1, bool pin) {
         if (NOISE == NOISE_NONE) return;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
+                if (ni < ni0 || ni >= ni1) continue;
                 const uint64_t grow = g.rng.row0 + (uint64_t)(m0 + wm * WM + slot * 4 + mi * 16);
                 uint32_t (&w)[4] = draws[(NOISE != NOISE_NONE) ? ni * TM + mi : 0];
                 philox4x32_10((uint32_t)(n0 + wn * WN + l15 + ni * 16), (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step,
                               g.rng.seed_lo, g.rng.seed_hi, w);
-                asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));   // drawn HERE, not sunk into the epilogue
+                if (pin) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));   // drawn HERE, not sunk into the epilogue
             }
     };
     float biasv[TN];   // loaded here too: in the epilogue its latency would be exposed
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
         TileRef rc = tile_of(t_begin), rn = tile_of(t_begin + 1);
         fetch(r0, rc);
         fetch(r1, rn);
-        draw_all();
+        draw_cols(0, DRAW_EARLY, true);
         park(r0, 0, rc, 0, NCH);
         __syncthreads();
         frag_a(0, 0, fa[0]);
@@ -400,6 +403,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void k_gemm_pb(GemmArgsB
     asm volatile("" : "+v"(colb));   // opaque: keeps the epilogue's address arithmetic out of the k loop's registers
     const int rowq = m0 + wm * WM + slot * 4;
     {
+        draw_cols(nt > 0 ? DRAW_EARLY : 0, TN, false);
         auto elementwise = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
