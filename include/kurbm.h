@@ -257,6 +257,11 @@ int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, 
                            int which, int stage, void* workspace, size_t workspace_bytes,
                            kurbm_stream_t stream);
 
+/* kurbm_cd_epoch on the x3 path: every batch of an epoch in one call (fused updates; returns the number of steps). */
+int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* V,
+                      int v_pieces, int n_rows, int ldv, int batch_size, const kurbm_cd_opts* opts,
+                      void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
 /* kurbm_apply_delta for the x3 path (data-parallel step): W, b_h, b_v += lr * delta AND the mirror's weight
  * pieces rewritten, in one launch. */
 int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,

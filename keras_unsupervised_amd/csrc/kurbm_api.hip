@@ -971,6 +971,24 @@ int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, 
                        stage);
 }
 
+int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* V,
+                      int v_pieces, int n_rows, int ldv, int batch_size, const kurbm_cd_opts* opts, void* workspace,
+                      size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx || !opts) return fail(KURBM_ERR_ARG, "null argument");
+    if (n_rows < 0 || batch_size <= 0) return fail(KURBM_ERR_ARG, "bad row count / batch size");
+    if (opts->delta_out || !opts->apply) return fail(KURBM_ERR_ARG, "kurbm_cd_epoch_x3 applies in place: apply = 1, delta_out = null");
+    kurbm_cd_opts o = *opts;
+    int steps = 0;
+    for (int lo = 0; lo < n_rows; lo += batch_size, ++steps) {
+        const int rows = (n_rows - lo < batch_size) ? n_rows - lo : batch_size;
+        if (int e = cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, V + (size_t)lo * ldv, rows, ldv, &o, 7, workspace,
+                                workspace_bytes, stream))
+            return e;
+        ++o.step;
+    }
+    return steps;
+}
+
 int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* delta,
                          float lr, int which, kurbm_stream_t stream) {
     if (!ctx || !delta) return fail(KURBM_ERR_ARG, "null argument");

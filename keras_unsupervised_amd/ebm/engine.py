@@ -268,8 +268,25 @@ class DeviceRBM:
             if stage == 5:
                 self._weights_written(kept=3)
 
-    def cd_epoch(self, v, n_rows, batch_size, lr, seed, step0, k=1, mode=MODE_VISIBLE_BERNOULLI, v_chain=None):
-        """All batches of one epoch in ONE library call (fp32, fused updates, no score); returns #steps."""
+    def cd_epoch(self, v, n_rows, batch_size, lr, seed, step0, k=1, mode=MODE_VISIBLE_BERNOULLI, v_chain=None,
+                 compute="fp32"):
+        """All batches of one epoch in ONE library call (fused updates, no score); returns #steps."""
+        if compute == "x3":
+            with torch.cuda.device(self.device):
+                vp = self.v_pieces(v)
+                if v_chain is not None and vp == 1:
+                    vp = self.v_pieces(v_chain)
+                rows = min(batch_size, max(n_rows, 1))
+                mir, ws = self.mirror(3), self.workspace_bf16(rows, k, 3, vp)
+                opts = CdOpts(int(k), int(mode), float(lr), 1, None, v_chain.ptr() if v_chain is not None else None,
+                              int(seed), 0, int(step0) & 0xFFFFFFFF, 0)
+                n = self.lib.kurbm_cd_epoch_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), v.ptr(), vp,
+                                               int(n_rows), v.ld, int(batch_size), C.byref(opts), ws.data_ptr(), ws.numel(),
+                                               self._stream())
+                if n < 0:
+                    check(n)
+            self._weights_written(kept=3)
+            return n
         with torch.cuda.device(self.device):
             ws = self.workspace(min(batch_size, max(n_rows, 1)), k)
             opts = CdOpts(int(k), int(mode), float(lr), 1, None, v_chain.ptr() if v_chain is not None else None,

@@ -247,15 +247,16 @@ class RBM(object):
             first = min(bs, n)
             self._v_chain.t[:first].copy_(Vd.t[:first])
 
-        # quiet single-GPU fused fp32 training: the whole batch loop of an epoch is one library call
+        # quiet single-GPU fused training (fp32 MFMA or x3): the whole batch loop of an epoch is one library call
         whole_epochs = (verbose != 1 and world == 1 and self.update_mode == "fused"
-                        and self._compute() == "fp32")
+                        and self._compute() in ("fp32", "x3"))
         for epoch in range(int(self.hps["epochs"])):                              # rbm.py:113
             if verbose == 1:
                 print(epoch + 1, "/", self.hps["epochs"], " epochs", end="\r")   # rbm.py:115
             if whole_epochs:
                 self._update_count += d.cd_epoch(Vd, n, bs, lr, self.seed, self._update_count, k=self.cd_k,
-                                                 mode=self.mode, v_chain=self._v_chain if self.persistent else None)
+                                                 mode=self.mode, v_chain=self._v_chain if self.persistent else None,
+                                                 compute=self._compute())
                 continue
             for i in range(num_step):                                            # rbm.py:163
                 lo, hi = i * bs, min((i + 1) * bs, n)                            # rbm.py:211 / :218

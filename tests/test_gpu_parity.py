@@ -484,6 +484,20 @@ def test_bf16_rbm_fit(gpu_device):
     assert not np.array_equal(a.rbm_weight, b.rbm_weight)
 
 
+def test_x3_epoch_call_equals_step_loop(gpu_device):
+    """kurbm_cd_epoch_x3 (one call per epoch) and the per-step host loop give bit-identical parameters."""
+    nv, nh = 72, 40
+    W0 = synthetic_params(nv, nh, seed=700)
+    V = synthetic_binary(150, nv, seed=701, p=0.3)
+    a, b = _engine(*W0, gpu_device), _engine(*W0, gpu_device)
+    vd = _dm(V, gpu_device)
+    assert a.cd_epoch(vd, 150, 64, 0.01, 9, 5, k=2, compute="x3") == 3
+    for i, (lo, hi) in enumerate(O.batch_slices(150, 64)):
+        b.cd_step(vd, hi - lo, lo, 0.01, 9, 5 + i, k=2, compute="x3")
+    for x, y in zip(a.get_weights(), b.get_weights()):
+        assert np.array_equal(x, y)
+
+
 def test_epoch_call_equals_step_loop(gpu_device):
     """kurbm_cd_epoch (one call per epoch) and the per-step host loop give bit-identical parameters."""
     nv, nh = 72, 40
