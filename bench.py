@@ -213,6 +213,10 @@ def main():
                         "note": "executed bf16 MFMA flop (the pieces: 3 per half step, 1 + 3 for the statistics) against the dense "
                                 "bf16 peak; algorithmic fp32 flop/s of the same launch in kernels[...].algorithmic_tflops",
                         "traffic": traffic_all.get(dom, {}).get("hbm_bytes_per_launch"),
+                        "algorithmic": {"achieved": kern_x3[dom]["algorithmic_tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": kern_x3[dom]["algorithmic_tflops"] / PEAK_F32_MFMA_TFLOPS,
+                                        "note": "SURVEY 8(d) algorithmic fp32 flop of this launch (4 B V H for the statistics, "
+                                                "2 B V H per half step) against the fp32 MFMA peak the north star names"},
                         "kernels": kern_x3, "kernels_fp32_path": kern}
         else:
             dom = max((k for k in kern if k != "outer_stats_gemm_plus_reduce"), key=lambda k: kern[k]["ms"])

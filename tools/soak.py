@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 from keras_unsupervised_amd.ebm.engine import DeviceMatrix, DeviceRBM  # noqa: E402
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--compute", default="x3", choices=("x3", "fp32", "bf16"))
 ap.add_argument("--steps", type=int, default=3000)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -29,7 +30,7 @@ for run in range(2):
     eng = DeviceRBM(W0, np.zeros(NH, np.float32), np.zeros(NV, np.float32), dev)
     t0 = time.perf_counter()
     for i in range(a.steps):
-        eng.cd_step(V, B, (i % 8) * B, 1e-3 / B, 42, i)
+        eng.cd_step(V, B, (i % 8) * B, 1e-3 / B, 42, i, compute=a.compute)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     W, bh, bv = eng.get_weights()
