@@ -14,7 +14,8 @@
 // real-valued A (grey-level data) is three segments (ia = 0, 1, 2 with npb = 3, 2, 1).
 //
 // Tile 128 x 128, k-tile 64 (swizzled 128-byte LDS rows), 8 waves (2 x 4, 64 x 32 outputs each), two per SIMD: while one waits for
-// LDS or the barrier the other issues MFMAs.  Staging global -> registers -> LDS with buffer loads (a
+// LDS or the barrier the other issues MFMAs.  B fragments are read two micro-steps ahead; the eight loads of a
+// tile are issued one part per micro-step.  Staging global -> registers -> LDS with buffer loads (a
 // constant per-lane offset + one scalar offset per tile: no vector address arithmetic in the loop),
 // double-buffered in LDS, fetched two tiles ahead, one barrier per tile.
 //
@@ -23,10 +24,11 @@
 // rows of its column); only the row-major bf16 plane takes a trip through LDS (bf16 patch of the whole
 // tile, then 16-byte coalesced rows).
 //
-// Measured limits (MI355X, config 2): the k loop runs at ~45 % of the bf16 MFMA
-// rate; L2 hit rate 70 % (half steps) / 20 % (statistics): the operands stream from the Infinity Cache.
-// A variant with the pieces loaded straight into registers (no LDS for B) was 15 % slower, padding the
-// leading dimensions and staggering the k walk of neighbouring workgroups changed nothing.
+// Measured (MI355X, config 2): a half step is 29-31 us (prologue 4, k loop 18 at ~1.3 PFLOP/s,
+// draw + sigmoid 2, plane stores 4), the statistics GEMM 38 us; 645-685 executed bf16 TFLOP/s per launch.  L2 hit
+// rate 75 %: every XCD pulls all weight pieces.  Tried and dropped (git history): pieces loaded straight into
+// registers without LDS (15 % slower), padded leading dimensions, staggered k walks, row-tile-fastest block order
+// (all equal), Philox calls spread over the k loop through wave-uniform selects (scratch).
 //
 // Reference op sequences: ku/ebm/rbm.py:46-47 (v->h), :52-53 / :121-123 (h->v), :124 (h_neg), :125-134
 // (statistics); the split is an implementation choice of this build.
