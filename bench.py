@@ -123,8 +123,11 @@ def main():
         if world == 1 and not force_dp:
             eng.cd_step(V, BATCH, lo, lr, seed, i, compute=args.compute)
         else:
-            eng.cd_step(V, BATCH, lo, lr, seed, i, apply=False, emit_delta=True, row0=rank * BATCH, compute=args.compute)
-            dp.allreduce_sum_(eng.delta_buffer())
+            if args.compute == "x3" and dp.OVERLAP_ROW_RANGES:
+                dp.x3_sums_overlapped(eng, V, BATCH, lo, lr, seed, i, row0=rank * BATCH)
+            else:
+                eng.cd_step(V, BATCH, lo, lr, seed, i, apply=False, emit_delta=True, row0=rank * BATCH, compute=args.compute)
+                dp.allreduce_sum_(eng.delta_buffer())
             eng.apply_delta(lr, compute=args.compute)
 
     for i in range(args.warmup):

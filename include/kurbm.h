@@ -262,6 +262,21 @@ int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_
                       int v_pieces, int n_rows, int ldv, int batch_size, const kurbm_cd_opts* opts,
                       void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
 
+/*
+ * The data-parallel x3 step in pieces, so that the all-reduce of the first rows of dW can run while the rest is
+ * still being computed:  kurbm_cd_chain_x3 = the chain alone (v_pos -> bf16, the three half steps; leaves the
+ * states in `workspace`);  kurbm_x3_stats_rows = the statistics of visible rows [m_lo, m_hi) of that chain into
+ * opts->delta_out (packed [dW | db_h | db_v]; rows m_lo .. m_hi-1 of dW, and with m_hi == n_vis also db_h and
+ * db_v).  m_lo a multiple of 128; opts->apply = 0.  Calling it for [0, m) and [m, n_vis) gives the delta of
+ * kurbm_cd_step_x3(apply = 0) up to the order of the fp32 additions (the split-K slicing differs).
+ */
+int kurbm_cd_chain_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
+                      int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, void* workspace,
+                      size_t workspace_bytes, kurbm_stream_t stream);
+int kurbm_x3_stats_rows(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                        const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, int m_lo,
+                        int m_hi, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
 /* kurbm_apply_delta for the x3 path (data-parallel step): W, b_h, b_v += lr * delta AND the mirror's weight
  * pieces rewritten, in one launch. */
 int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,

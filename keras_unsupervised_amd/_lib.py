@@ -68,6 +68,8 @@ SIGNATURES = {
     "kurbm_cd_step_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _vp, _sz, _vp]),
     "kurbm_cd_step_x3_stage": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _i, _vp, _sz, _vp]),
     "kurbm_cd_epoch_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _i, _OP, _vp, _sz, _vp]),
+    "kurbm_cd_chain_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _vp, _sz, _vp]),
+    "kurbm_x3_stats_rows": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _i, _vp, _sz, _vp]),
     "kurbm_x3_apply_delta": (_i, [_vp, _PP, _vp, _sz, _vp, C.c_float, _i, _vp]),
     "kurbm_half_step_x3": (_i, [_vp, _PP, _vp, _sz, _i, _vp, _i, _i, _i, _i, _i, _RP, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "kurbm_bf16_exact": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

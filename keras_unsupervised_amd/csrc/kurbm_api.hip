@@ -548,7 +548,7 @@ struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_spli
 
 // pb: the statistics run on k_gemm_pb (x3): k-tile 64, one workgroup per CU, nseg segments walked
 // fastest, so a slice is a whole number of k positions
-static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, bool pb) {
+static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, bool pb, int s_max = 1 << 30) {
     OuterPlanB pl;
     const bool bn64 = pb && env_int("KURBM_X3_BN", 128) == 64;
     pl.gm = ceil_div(n_vis, 128);
@@ -556,6 +556,7 @@ static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int
     pl.nkt = round_up(rows, 128) / (pb ? 64 : 128);
     pl.kt_total = nseg * pl.nkt;
     int s = env_int("KURBM_BF16_SPLIT", ((pb && !bn64 ? 1 : 2) * ctx->ncu) / (pl.gm * pl.gn));
+    if (s > s_max) s = s_max;
     if (s < 1) s = 1;
     if (s > pl.nkt) s = pl.nkt;
     pl.nsplit_bound = s;
@@ -748,10 +749,13 @@ static int half_step_any(kurbm_ctx* ctx, int pieces, int in_pieces, const kurbm_
 
 static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                        const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace,
-                       size_t workspace_bytes, kurbm_stream_t stream, int only = -1) {
-    // `only` >= 0 (measurement hook kurbm_cd_step_x3_stage): launch just that stage of the sequence, on
-    // the planes a previous complete step left in the workspace
-#define KURBM_STAGE(n) (only < 0 || only == (n))
+                       size_t workspace_bytes, kurbm_stream_t stream, int only = -1, int m_lo = 0, int m_hi = -1) {
+    // `only` 0..6 (measurement hook kurbm_cd_step_x3_stage): launch just that stage of the sequence, on the planes a
+    // previous complete step left in the workspace.  8: the chain alone (stages 0-3, kurbm_cd_chain_x3).  7: the
+    // statistics of visible rows [m_lo, m_hi) alone (stages 4-5, kurbm_x3_stats_rows) -- the data-parallel step
+    // all-reduces the first rows of dW while the rest is still being computed.
+#define KURBM_STAGE(n) (only < 0 || only == (n) || (only == 8 && (n) <= 3) || (only == 7 && ((n) == 4 || (n) == 5)))
+    if (m_hi < 0) m_hi = p ? p->n_vis : 0;
     if (!ctx || !o) return fail(KURBM_ERR_ARG, "null argument");
     if (int e = check_params(p)) return e;
     if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
@@ -843,17 +847,25 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
 
     // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
     // segments: (piece of v_pos) x h_pos, then v_neg x (piece of h_neg), negated
-    const OuterPlanB pl = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, pieces == 3 ? v_pieces + 1 : 2, pieces == 3);
+    const int nseg_st = pieces == 3 ? v_pieces + 1 : 2;
+    const OuterPlanB plf = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, nseg_st, pieces == 3);
+    const int Mr = m_hi - m_lo;                         // visible rows of this call (all of them unless only == 7)
+    const bool sub = (Mr != p->n_vis);
+    // a row range keeps inside the slab memory carved for the whole matrix
+    const OuterPlanB pl = sub ? plan_outer_bf16(ctx, rows, Mr, p->n_hid, nseg_st, pieces == 3,
+                                                (int)((w.slab_stride * plf.nsplit_bound) / ((size_t)Mr * plf.ld_slab)))
+                              : plf;
+    const size_t slab_stride = sub ? (size_t)Mr * pl.ld_slab : w.slab_stride;
     int nslab_used = pl.nsplit;
     if (need_w && KURBM_STAGE(4)) {
         GemmArgsB g;
         memset(&g, 0, sizeof g);
-        g.A0 = w.vbT; g.a_plane0 = w.planeVT; g.B0 = w.hbT;
-        g.A1 = w.v2bT; g.B1 = w.hnT; g.b_plane1 = w.planeHT;
+        g.A0 = w.vbT + (size_t)m_lo * w.Lb; g.a_plane0 = w.planeVT; g.B0 = w.hbT;
+        g.A1 = w.v2bT + (size_t)m_lo * w.Lb; g.B1 = w.hnT; g.b_plane1 = w.planeHT;
         g.lda = w.Lb; g.ldb = w.Lb;
-        g.M = p->n_vis; g.N = p->n_hid; g.K = w.Kb;
+        g.M = Mr; g.N = p->n_hid; g.K = w.Kb;
         g.grid_m = pl.gm; g.grid_n = pl.gn;
-        g.slab = w.slab; g.slab_stride = w.slab_stride; g.ld_slab = pl.ld_slab;
+        g.slab = w.slab; g.slab_stride = slab_stride; g.ld_slab = pl.ld_slab;
         if (pb) {   // (piece of v_pos) x h_pos, then v_neg x (all pieces of h_neg), walked segment-fastest
             g.nseg = pb_codes(v_pieces, 1, 0u, &g.seg_codes, 0);
             g.nseg = pb_codes(1, 3, 1u, &g.seg_codes, g.nseg);
@@ -876,20 +888,22 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     }
     ReduceArgs a;
     memset(&a, 0, sizeof a);
-    a.slab = w.slab; a.slab_stride = w.slab_stride; a.ld_slab = pl.ld_slab;
+    a.slab = w.slab; a.slab_stride = slab_stride; a.ld_slab = pl.ld_slab;
     a.nslab = nslab_used;
-    a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw;
-    a.nblk_w = need_w ? (int)(((long long)p->n_vis * (pl.ld_slab / 4) + 255) / 256) : 0;
+    a.n_vis = Mr; a.n_hid = p->n_hid; a.ldw = p->ldw;
+    a.nblk_w = need_w ? (int)(((long long)Mr * (pl.ld_slab / 4) + 255) / 256) : 0;
     a.lr = o->lr;
     const bool ap = o->apply != 0;
     a.W = (ap && (which & 1)) ? p->W : nullptr;
-    a.delta_w = o->delta_out;
+    a.delta_w = o->delta_out ? o->delta_out + (size_t)m_lo * p->n_hid : nullptr;
     a.part_h = w.part_h; a.nrow_tiles_h = pb ? 4 * gm_h : gm_h; a.ld_part_h = w.ldh32;
     a.b_h = (ap && (which & 2)) ? p->b_h : nullptr;
     a.delta_bh = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid : nullptr;
     a.part_v = w.part_v; a.nrow_tiles_v = pb ? gp_v + 2 * gm_v : gm_v; a.ld_part_v = w.ldv32;
     a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
     a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
+    if (sub && m_hi != p->n_vis) { a.part_h = nullptr; a.part_v = nullptr; }   // the bias sums leave with the LAST rows
+    if (sub) a.n_vis_bias = p->n_vis;
     if (a.W && need_w && !env_int("KURBM_UNFUSED_MIRROR", 0)) {
         // the fp32 master moves: the slab reduction writes the new weights AND their bf16 pieces in one launch
         a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
@@ -987,6 +1001,23 @@ int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_
         ++o.step;
     }
     return steps;
+}
+
+int kurbm_cd_chain_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
+                      int v_pieces, int rows, int ldv, const kurbm_cd_opts* o, void* workspace, size_t workspace_bytes,
+                      kurbm_stream_t stream) {
+    return cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, 7, workspace, workspace_bytes, stream, 8);
+}
+
+int kurbm_x3_stats_rows(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
+                        int v_pieces, int rows, int ldv, const kurbm_cd_opts* o, int m_lo, int m_hi, void* workspace,
+                        size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!p || !o) return fail(KURBM_ERR_ARG, "null argument");
+    if (o->apply || !o->delta_out) return fail(KURBM_ERR_ARG, "kurbm_x3_stats_rows emits sums: apply = 0, delta_out set");
+    if (m_lo < 0 || m_hi > p->n_vis || m_lo >= m_hi || (m_lo & 127))
+        return fail(KURBM_ERR_ARG, "row range: 0 <= m_lo < m_hi <= n_vis, m_lo a multiple of 128");
+    return cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, 7, workspace, workspace_bytes, stream, 7,
+                       m_lo, m_hi);
 }
 
 int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* delta,

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int ti
             if (a.delta_bh) a.delta_bh[q] = v;
             if (a.b_h) a.b_h[q] += a.lr * v;
         }
-    } else if (q < a.n_hid + a.n_vis) {
+    } else if (q < a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis)) {
         const int col = q - a.n_hid;
         if (a.part_v) {
             const float v = colsum(a.part_v, a.nrow_tiles_v, a.ld_part_v, col);
@@ -656,7 +656,7 @@ hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st) {
     if (a.Wb && a.ldWb > c_ext) c_ext = a.ldWb;
     if (a.Wtb && a.ldWtb > r_ext) r_ext = a.ldWtb;
     const int tiles_x = (c_ext + CVT - 1) / CVT, tiles_y = (r_ext + 15) / 16;
-    const int nb = (a.n_hid + a.n_vis + 255) / 256;
+    const int nb = (a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis) + 255) / 256;
     hipLaunchKernelGGL(k_reduce_apply_split, dim3(tiles_x * tiles_y + nb), dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y);
     return hipGetLastError();
 }

@@ -68,7 +68,8 @@ struct ReduceArgs {
     const float* slab;
     size_t slab_stride;
     int nslab, ld_slab;
-    int n_vis, n_hid, ldw;
+    int n_vis, n_hid, ldw;   // n_vis: rows of the slabs / of W handled by this launch
+    int n_vis_bias;          // visible units of the bias partials when that differs (row-range launch); 0 = n_vis
     int nblk_w;
     // tile-ordered visit (tile_bm > 0): nblk_w = grid_m * grid_n * parts blocks, same XCD order as the GEMM
     int tile_bm, tile_bn, grid_m, grid_n, parts, m_fastest;

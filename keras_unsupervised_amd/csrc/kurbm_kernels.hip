@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
             if (a.delta_bh) a.delta_bh[q] = t;
             if (a.b_h) a.b_h[q] += a.lr * t;
         }
-    } else if (q < a.n_hid + a.n_vis) {
+    } else if (q < a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis)) {
         const int c = q - a.n_hid;
         if (a.part_v) {
             const float t = colsum(a.part_v, a.nrow_tiles_v, a.ld_part_v, c);
@@ -805,7 +805,7 @@ hipError_t launch_philox_uniform(float* out, int rows, int cols, int ld, const R
 }
 
 hipError_t launch_reduce_apply(const ReduceArgs& a, hipStream_t st) {
-    const int nb = (a.n_hid + a.n_vis + 255) / 256;
+    const int nb = (a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis) + 255) / 256;
     hipLaunchKernelGGL(k_reduce_apply, dim3(a.nblk_w + nb), dim3(256), 0, st, a);
     return hipGetLastError();
 }

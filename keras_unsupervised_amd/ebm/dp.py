@@ -13,6 +13,14 @@ import torch
 import torch.distributed as dist
 
 
+import os
+
+# Off by default.  Measured on one MI355X (tools/dp_step_times.py, config 2): the statistics of rows [0,384) and
+# [384,784) take 25.6 + 33.9 us against 46.2 us in one piece, so hiding the first all-reduce (~30 us of an estimated
+# ~56 us at 8 GPUs) under the second range nets ~3 us, and the extra launches make the step host-bound.
+OVERLAP_ROW_RANGES = os.environ.get("KURBM_DP_OVERLAP", "0") == "1"
+
+
 def world():
     """(rank, world_size) of the default process group, (0, 1) when not distributed."""
     if dist.is_available() and dist.is_initialized():
@@ -60,3 +68,24 @@ def pack(dW, db_h, db_v, out=None):
     b.copy_(db_h)
     c.copy_(db_v)
     return out
+
+
+def x3_sums_overlapped(eng, v, rows, row_start, lr, seed, step, k=1, row0=0, v_chain=None, v_chain_row=0):
+    """Data-parallel x3 step up to the summed delta: the chain, then the statistics in two row ranges of dW,
+    the all-reduce of the first range running while the second is still being computed.  Leaves the all-reduced
+    packed sums in eng.delta_buffer().  (Without a process group the all-reduces are no-ops.)"""
+    nv, nh = eng.n_vis, eng.n_hid
+    delta = eng.delta_buffer()
+    eng.cd_chain_x3(v, rows, row_start, lr, seed, step, k=k, row0=row0, v_chain=v_chain, v_chain_row=v_chain_row)
+    m = (nv // 2) // 128 * 128
+    if m < 128:                                   # too few visible rows to split on a tile boundary
+        eng.x3_stats_rows(v, rows, row_start, 0, nv, lr, seed, step, k=k, row0=row0)
+        allreduce_sum_(delta)
+        return
+    eng.x3_stats_rows(v, rows, row_start, 0, m, lr, seed, step, k=k, row0=row0)
+    w1 = allreduce_sum_(delta[: m * nh], async_op=True)
+    eng.x3_stats_rows(v, rows, row_start, m, nv, lr, seed, step, k=k, row0=row0)
+    w2 = allreduce_sum_(delta[m * nh:], async_op=True)
+    for w in (w1, w2):
+        if w is not None:
+            w.wait()

@@ -255,6 +255,31 @@ class DeviceRBM:
             else:
                 raise ValueError("compute must be 'fp32', 'x3' or 'bf16', got %r" % (compute,))
 
+    def _x3_opts(self, v, rows, k, lr, seed, step, chain, row0, v_chain, v_chain_row):
+        vp = self.v_pieces(v)
+        if v_chain is not None and vp == 1:
+            vp = self.v_pieces(v_chain)
+        opts = CdOpts(int(k), MODE_VISIBLE_BERNOULLI, float(lr), 0, self.delta_buffer().data_ptr(),
+                      v_chain.ptr(v_chain_row) if v_chain is not None else None,
+                      int(seed), int(row0), int(step) & 0xFFFFFFFF, int(chain))
+        return vp, opts, self.mirror(3), self.workspace_bf16(rows, k, 3, vp)
+
+    def cd_chain_x3(self, v, rows, row_start, lr, seed, step, k=1, chain=0, row0=0, v_chain=None, v_chain_row=0):
+        """The Gibbs chain of an x3 step alone (data-parallel step: statistics follow through x3_stats_rows)."""
+        with torch.cuda.device(self.device):
+            vp, opts, mir, ws = self._x3_opts(v, rows, k, lr, seed, step, chain, row0, v_chain, v_chain_row)
+            check(self.lib.kurbm_cd_chain_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                             v.ptr(row_start), vp, rows, v.ld, C.byref(opts), ws.data_ptr(), ws.numel(),
+                                             self._stream()))
+
+    def x3_stats_rows(self, v, rows, row_start, m_lo, m_hi, lr, seed, step, k=1, chain=0, row0=0):
+        """Packed sums of visible rows [m_lo, m_hi) of the chain cd_chain_x3 left in the workspace -> delta_buffer()."""
+        with torch.cuda.device(self.device):
+            vp, opts, mir, ws = self._x3_opts(v, rows, k, lr, seed, step, chain, row0, None, 0)
+            check(self.lib.kurbm_x3_stats_rows(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                               v.ptr(row_start), vp, rows, v.ld, C.byref(opts), int(m_lo), int(m_hi),
+                                               ws.data_ptr(), ws.numel(), self._stream()))
+
     def cd_step_x3_stage(self, v, rows, row_start, lr, seed, step, stage):
         """Measurement hook (bench.py): ONE launch of the x3 CD-1 sequence on the planes the previous
         complete x3 step left in the workspace; stage numbering as kurbm_cd_step_x3_stage."""

@@ -298,14 +298,19 @@ class RBM(object):
         d = self._dev
         s_lo, s_hi = dp.shard_rows(rows, world, rank)
         delta = d.delta_buffer()
-        if s_hi > s_lo:
-            d.cd_step(Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,
-                      chain=CHAIN_W, apply=False, emit_delta=True, row0=s_lo,
-                      v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo,
-                      compute=self._compute())
+        if s_hi > s_lo and self._compute() == "x3" and dp.OVERLAP_ROW_RANGES:
+            # chain, then dW in two row ranges: the first all-reduce overlaps the second range's GEMM
+            dp.x3_sums_overlapped(d, Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, row0=s_lo,
+                                  v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo)
         else:
-            delta.zero_()
-        dp.allreduce_sum_(delta)
+            if s_hi > s_lo:
+                d.cd_step(Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,
+                          chain=CHAIN_W, apply=False, emit_delta=True, row0=s_lo,
+                          v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo,
+                          compute=self._compute())
+            else:
+                delta.zero_()
+            dp.allreduce_sum_(delta)
         d.apply_delta(lr, compute=self._compute())
 
     # ------------------------------------------------------------------ config ----------

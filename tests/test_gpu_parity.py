@@ -707,3 +707,22 @@ def test_x3_rbm_fit_trajectory_golden(gpu_device, golden_dir):
         assert np.max(np.abs(r.rbm_weight - g["W_" + um])) <= TOL
         assert np.max(np.abs(r.hidden_bias - g["bh_" + um])) <= TOL
         assert np.max(np.abs(r.visible_bias - g["bv_" + um])) <= TOL
+
+
+def test_x3_overlapped_dp_sums_equal_one_shot(gpu_device):
+    """dp.x3_sums_overlapped (chain, then dW in two row ranges) leaves the same packed sums as one
+    kurbm_cd_step_x3(apply=0): draws identical, sums equal up to the order of the fp32 additions."""
+    from keras_unsupervised_amd.ebm import dp
+    for (B, nv, nh, k) in ((300, 784, 256, 1), (260, 300, 200, 2), (64, 100, 80, 1)):
+        W0 = synthetic_params(nv, nh, seed=1100 + B)
+        V = synthetic_binary(B, nv, seed=1101 + B, p=0.3)
+        e = _engine(*W0, gpu_device)
+        vd = _dm(V, gpu_device)
+        ref = _gpu_cd_delta(e, vd, B, 0.01, 5, 3, k=k, compute="x3")
+        dp.x3_sums_overlapped(e, vd, B, 0, 0.01, 5, 3, k=k)
+        torch.cuda.synchronize()
+        got = e.delta_buffer().cpu().numpy()
+        dW, dbh, dbv = _split(got, nv, nh)
+        rW, rbh, rbv = _split(ref, nv, nh)
+        assert np.max(np.abs(dW - rW)) <= 1e-4 * max(1.0, float(np.abs(rW).max()))
+        assert np.array_equal(dbv, rbv) and np.allclose(dbh, rbh, rtol=0, atol=1e-4 * max(1.0, float(np.abs(rbh).max())))
