@@ -171,15 +171,16 @@ __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int ti
     }
     // bias partials [row tiles][columns] -> column sums: eight loads in flight per lane, fixed order
     const int q = ((int)blockIdx.x - tiles) * 256 + t;
+    // in double: the rows are +sum(h_pos) ... -sum(h_neg) per 64 batch rows, two large totals that cancel
     auto colsum = [](const float* __restrict__ part, int ntiles, int ld, int col) {
-        float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        double u[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
         int i = 0;
         for (; i + 8 <= ntiles; i += 8) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) u[e] += part[(size_t)(i + e) * ld + col];
+            for (int e = 0; e < 8; ++e) u[e] += (double)part[(size_t)(i + e) * ld + col];
         }
-        for (; i < ntiles; ++i) u[0] += part[(size_t)i * ld + col];
-        return ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+        for (; i < ntiles; ++i) u[0] += (double)part[(size_t)i * ld + col];
+        return (float)(((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7])));
     };
     if (q < a.n_hid) {
         if (a.part_h) {

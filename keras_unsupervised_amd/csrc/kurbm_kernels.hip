@@ -689,15 +689,17 @@ __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
     // bias partials [row tiles][columns] -> column sums: eight loads in flight per lane, partial sums
     // combined in a fixed order (bit-reproducible)
     const int q = ((int)blockIdx.x - a.nblk_w) * 256 + tid;
+    // accumulated in double: on the x3 path the rows are +sum(h_pos) ... -sum(h_neg) per 64 batch rows, two large
+    // totals that cancel, and an fp32 running sum would lose ~1e-4 of the difference
     auto colsum = [](const float* __restrict__ part, int ntiles, int ld, int c) {
-        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        double t[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
         int r = 0;
         for (; r + 8 <= ntiles; r += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] += part[(size_t)(r + u) * ld + c];
+            for (int u = 0; u < 8; ++u) t[u] += (double)part[(size_t)(r + u) * ld + c];
         }
-        for (; r < ntiles; ++r) t[0] += part[(size_t)r * ld + c];
-        return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        for (; r < ntiles; ++r) t[0] += (double)part[(size_t)r * ld + c];
+        return (float)(((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])));
     };
     if (q < a.n_hid) {
         if (a.part_h) {

@@ -726,3 +726,50 @@ def test_x3_overlapped_dp_sums_equal_one_shot(gpu_device):
         rW, rbh, rbv = _split(ref, nv, nh)
         assert np.max(np.abs(dW - rW)) <= 1e-4 * max(1.0, float(np.abs(rW).max()))
         assert np.array_equal(dbv, rbv) and np.allclose(dbh, rbh, rtol=0, atol=1e-4 * max(1.0, float(np.abs(rbh).max())))
+
+
+def test_x3_random_shape_sweep(gpu_device):
+    """The seeded sweep of awkward shapes (tiny and ragged batches, unit counts that are not multiples of 4 / 16 /
+    64 / the tiles, k of every residue class, 0/1 and real-valued data, CD-1 / CD-2, with and without persistent
+    chains) on the x3 path: half steps and CD-k sums against the fp32 oracle, fp32 bars; in-place apply and the
+    data-parallel apply (fused weight-piece rewrite) agree."""
+    rs = np.random.RandomState(4052)
+    for case in range(16):
+        B = int(rs.choice([1, 2, 5, 31, 33, 63, 65, 100, 129, 200, 257, 300]))
+        nv = int(rs.randint(3, 500))
+        nh = int(rs.randint(3, 500))
+        k = int(rs.choice([1, 1, 2]))
+        real = bool(case % 3 == 2)
+        pcd = bool(case % 4 == 3)
+        W, b_h, b_v = synthetic_params(nv, nh, seed=1900 + case)
+        v = synthetic_real(B, nv, seed=1950 + case) if real else synthetic_binary(B, nv, seed=1950 + case, p=0.4)
+        chain0 = synthetic_binary(B, nv, seed=1975 + case, p=0.5) if pcd else None
+        e = _engine(W, b_h, b_v, gpu_device)
+        vd = _dm(v, gpu_device)
+        rng = O.Rng(case, 7)
+        out = e.half_step_bf16("vh", vd, B, 0, 1, case, 0, 7, pieces=3)
+        check_half_step(out, *O.sample_hidden(v, W, b_h, rng, 0))
+        h = out["sample"].to_numpy()
+        out2 = e.half_step_bf16("hv", out["sample"], B, 0, 1, case, 1, 7, pieces=3)
+        check_half_step(out2, *O.sample_visible(h, W, b_v, rng, 1))
+        cd = _dm(chain0, gpu_device) if pcd else None
+        d = _gpu_cd_delta(e, vd, B, 0.01, case, 3, k=k, v_chain=cd, compute="x3")
+        _, _, _, ch, (dW_ref, dbh_ref, dbv_ref) = O.cd_step_fused(W, b_h, b_v, v, 0.01, case, 3, k=k, v_chain=chain0)
+        dW, dbh, dbv = _split(d, nv, nh)
+        tag = (case, B, nv, nh, k, real, pcd)
+        # the bias sums against float64 sums of the oracle's states (numpy's float32 row-by-row sum of 300
+        # probabilities is itself ~1e-4 off; the kernels add the 64-row partials in double)
+        dbh64 = ch["h_pos"].astype(np.float64).sum(0) - ch["h_neg"].astype(np.float64).sum(0)
+        dbv64 = v.astype(np.float64).sum(0) - ch["v_neg"].astype(np.float64).sum(0)
+        assert rel_err(dW, dW_ref) <= TOL and rel_err(dbh, dbh64) <= TOL and rel_err(dbv, dbv64) <= TOL, tag
+        if pcd:
+            assert np.array_equal(cd.to_numpy(), ch["v_neg"]), tag
+        # in-place apply (slab reduce writes W and its pieces) == emit + data-parallel apply (fused rewrite)
+        e2 = _engine(W, b_h, b_v, gpu_device)
+        e2.cd_step(vd, B, 0, 0.01, case, 3, k=k, v_chain=_dm(chain0, gpu_device) if pcd else None, compute="x3")
+        e.apply_delta(0.01, compute="x3")
+        for x, y in zip(e.get_weights(), e2.get_weights()):
+            assert np.max(np.abs(x - y)) <= 1e-6, tag
+        p1 = e.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=3)["prob"].to_numpy()      # reads the rewritten pieces
+        p2 = e2.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=3)["prob"].to_numpy()
+        assert np.max(np.abs(p1 - p2)) <= 1e-6, tag
