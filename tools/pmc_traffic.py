@@ -20,10 +20,12 @@ def load(path, counter):
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-label = {("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 1>", 256): "x3_half_step_vh_sample",
-         ("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 1>", 224): "x3_half_step_hv_sample",
-         ("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 0>", 256): "x3_half_step_vh_prob",
-         ("k_gemm_pb<128, 128, 2, 4, 64, 3, 1, 0>", 224): "x3_stats_gemm"}
+label = {}
+for ws in ("", ", true"):      # plain and wave-specialised instantiations
+    label[("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 1%s>" % ws, 256)] = "x3_half_step_vh_sample"
+    label[("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 1%s>" % ws, 224)] = "x3_half_step_hv_sample"
+    label[("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 0%s>" % ws, 256)] = "x3_half_step_vh_prob"
+    label[("k_gemm_pb<128, 128, 2, 4, 64, 3, 1, 0%s>" % ws, 224)] = "x3_stats_gemm"
 out = {}
 for key in sorted(set(fetch) | set(write)):
     name = label.get(key)
