@@ -386,6 +386,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
         return;
     }
     Regs r0, r1;   // (never touched by the MFMA waves of the WS build: they stage nothing)
+    if (WS) __builtin_amdgcn_s_setprio(2);   // the MFMA waves go first wherever a loader wave competes for issue
     if (nt > 0) {
         TileRef rc = tile_of(t_begin), rn = tile_of(t_begin + 1);
         if (!WS) {
