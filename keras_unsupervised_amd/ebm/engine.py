@@ -323,23 +323,27 @@ class DeviceRBM:
         self._weights_written()
         return n
 
-    def half_step_bf16(self, direction, x, rows, act, noise, seed, stream_id, step, row0=0, pieces=1):
-        """Test hook: one half step with bf16 products (pieces=3: exact split); fp32 planes (sample, prob, u)."""
+    def half_step_bf16(self, direction, x, rows, act, noise, seed, stream_id, step, row0=0, pieces=1, row_start=0,
+                       want_prob=True, want_u=True):
+        """One half step with bf16 products (pieces=3: the exact split, used by transform() on the x3 path; pieces=1:
+        rounded operands, a test hook); fp32 planes (sample, prob, u) as requested."""
         n_out = self.n_hid if direction == "vh" else self.n_vis
         with torch.cuda.device(self.device):
             xp = self.v_pieces(x) if pieces == 3 else 1
             mir, ws = self.mirror(pieces), self.workspace_bf16(rows, 1, pieces, xp if pieces == 3 else 1)
-            out = {k: DeviceMatrix.zeros(rows, n_out, self.device) for k in ("sample", "prob", "u")}
+            want = {"sample": bool(noise), "prob": bool(want_prob) or not noise, "u": bool(want_u) and bool(noise)}
+            out = {k: (DeviceMatrix.zeros(rows, n_out, self.device) if want[k] else None) for k in ("sample", "prob", "u")}
             rng = Rng(int(seed), int(row0), int(stream_id) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF)
-            tail = (act, noise, C.byref(rng), out["sample"].ptr() if noise else None, out["prob"].ptr(),
-                    out["u"].ptr() if noise else None, round_up(n_out, 4), ws.data_ptr(), ws.numel(), self._stream())
+            tail = (act, noise, C.byref(rng), out["sample"].ptr() if out["sample"] is not None else None,
+                    out["prob"].ptr() if out["prob"] is not None else None, out["u"].ptr() if out["u"] is not None else None,
+                    round_up(n_out, 4), ws.data_ptr(), ws.numel(), self._stream())
             d = 0 if direction == "vh" else 1
             if pieces == 3:
                 check(self.lib.kurbm_half_step_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), d,
-                                                  x.ptr(), xp, rows, x.ld, *tail))
+                                                  x.ptr(row_start), xp, rows, x.ld, *tail))
             else:
                 check(self.lib.kurbm_half_step_bf16(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), d,
-                                                    x.ptr(), rows, x.ld, *tail))
+                                                    x.ptr(row_start), rows, x.ld, *tail))
         return out
 
     def apply_delta(self, lr, which=WHICH_ALL, delta=None, compute=None):

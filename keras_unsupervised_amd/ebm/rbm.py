@@ -158,17 +158,23 @@ class RBM(object):
             out = m.to_numpy()
         return [out] if as_list else out
 
-    def _sample_hidden(self, x):
-        act, noise = hidden_site(self.mode)
-        out = self._dev.half_step("vh", x, x.rows, 0, act, noise, self.seed, STREAM_TRANSFORM, self._call_count)
+    def _half(self, direction, x, act, noise, stream_id):
+        # large Bernoulli-mode inputs (a whole data set between DBN layers) go through the x3 kernels too
+        if self.mode == MODE_VISIBLE_BERNOULLI and self.compute_dtype in ("auto", "x3") and x.rows >= 1024:
+            out = self._dev.half_step_bf16(direction, x, x.rows, act, noise, self.seed, stream_id, self._call_count, pieces=3,
+                                           want_prob=False, want_u=False)
+        else:
+            out = self._dev.half_step(direction, x, x.rows, 0, act, noise, self.seed, stream_id, self._call_count)
         self._call_count += 1
         return out["sample"]
 
+    def _sample_hidden(self, x):
+        act, noise = hidden_site(self.mode)
+        return self._half("vh", x, act, noise, STREAM_TRANSFORM)
+
     def _sample_visible(self, h):
         act, noise = visible_site(self.mode)
-        out = self._dev.half_step("hv", h, h.rows, 0, act, noise, self.seed, STREAM_INV_TRANSFORM, self._call_count)
-        self._call_count += 1
-        return out["sample"]
+        return self._half("hv", h, act, noise, STREAM_INV_TRANSFORM)
 
     def transform(self, v):
         """Sampled hidden states of v (transform_func, rbm.py:88-89 -> :46-48 / :58-60)."""

@@ -773,3 +773,22 @@ def test_x3_random_shape_sweep(gpu_device):
         p1 = e.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=3)["prob"].to_numpy()      # reads the rewritten pieces
         p2 = e2.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=3)["prob"].to_numpy()
         assert np.max(np.abs(p1 - p2)) <= 1e-6, tag
+
+
+def test_x3_transform_surface(gpu_device):
+    """transform / inv_transform on a large Bernoulli-mode input run on the x3 kernels: the samples equal those of the
+    fp32 MFMA kernels (same counters) except where |u - p| is inside the rounding band."""
+    from keras_unsupervised_amd.ebm import MODE_VISIBLE_BERNOULLI, RBM
+    nv, nh, N = 96, 80, 2048
+    W0 = synthetic_params(nv, nh, seed=1300)
+    V = synthetic_binary(N, nv, seed=1301, p=0.3)
+    a = RBM({"batch_size": 64, "epochs": 1, "lr": 0.01}, nh, mode=MODE_VISIBLE_BERNOULLI, seed=3, weights=W0, compute_dtype="fp32")
+    b = RBM({"batch_size": 64, "epochs": 1, "lr": 0.01}, nh, mode=MODE_VISIBLE_BERNOULLI, seed=3, weights=W0)
+    Ha, Hb = a.transform(V)[0], b.transform(V)[0]
+    assert Ha.shape == Hb.shape == (N, nh) and set(np.unique(Hb)) <= {0.0, 1.0}
+    assert (Ha != Hb).sum() <= 8          # borderline draws only
+    rng = O.Rng(3, 0)
+    _, _, h_ref = O.sample_hidden(V, *W0[:2], rng, 0x100)
+    assert (Hb != h_ref).sum() <= 8
+    Va, Vb = a.inv_transform(Ha)[0], b.inv_transform(Ha)[0]
+    assert (Va != Vb).sum() <= 8
