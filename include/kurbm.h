@@ -229,7 +229,9 @@ int kurbm_half_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
  * k-segment of the product per pair of pieces; 0/1 samples (h_pos, v_neg, the hidden and visible
  * states of a Bernoulli chain) are a single exact piece.  Products of pieces are exact in fp32, so the
  * result differs from an fp32 GEMM only in the order of the fp32 additions.  Same reference
- * operations as the fp32 entry points (rbm.py:46-47, :121-134); MODE_VISIBLE_BERNOULLI only.
+ * operations as the fp32 entry points (rbm.py:46-47, :121-134), both visible modes: with
+ * MODE_VISIBLE_GAUSSIAN (rbm.py:55-67, :139-159) the negative visibles are real-valued and travel as three
+ * pieces too (row-major for the next half step, transposed for the statistics).
  *
  * v_pieces: 1 promises that every element of v_batch (and of opts->v_chain) is exactly a bf16
  * value, which 0/1 data is (check with kurbm_bf16_exact); 3 splits the batch as well.  When both

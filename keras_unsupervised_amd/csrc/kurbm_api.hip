@@ -600,7 +600,8 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     auto take32 = [&](size_t n) { float* p = reinterpret_cast<float*>(b + off); off = align_up(off + n * 4); return p; };
     w.vb = take16(v_pieces * w.planeV);    w.vbT = take16(v_pieces * w.planeVT);     // v_pos, both orientations
     w.hb = take16((size_t)w.Kb * w.Lh);    w.hbT = take16((size_t)n_hid * w.Lb);     // h_pos
-    w.v2b = take16((size_t)w.Kb * w.Lv);   w.v2bT = take16((size_t)n_vis * w.Lb);    // v_t / v_neg
+    w.v2b = take16((pieces == 3 ? 3 : 1) * w.planeV);                                // v_t / v_neg (x3: room for the three
+    w.v2bT = take16((pieces == 3 ? 3 : 1) * w.planeVT);                              //  pieces of Gaussian visibles)
     w.h2b = take16((size_t)w.Kb * w.Lh);                                             // h_t (k > 1, chain start)
     w.hnT = take16(pieces * w.planeHT);                                              // h_neg probabilities, transposed
     w.cb = take16(v_pieces * w.planeV);                                              // persistent chain as bf16
@@ -634,6 +635,7 @@ static int pair_codes(int a_pieces, int b_pieces, unsigned set, unsigned long lo
 // optional outputs and side products of a bf16 half step
 struct HalfOutB {
     uint16_t* out = nullptr; int ldo = 0;                 // bf16 value plane, row-major
+    int out_pieces = 1; size_t out_plane = 0;             // (x3, real-valued plane: its three pieces)
     uint16_t* outT = nullptr; int ldoT = 0;               // ... transposed
     int outT_pieces = 1; size_t outT_plane = 0;
     float* out_f32 = nullptr; float* prob_f32 = nullptr; float* out_u = nullptr; int ldo32 = 0;
@@ -666,6 +668,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.act = act; g.noise = noise;
         if (rng) g.rng = *rng;
         g.out = o.out; g.ldo = o.ldo; g.ldo_cols = o.out ? o.ldo : g.N;
+        g.out_pieces = o.out_pieces; g.out_plane = o.out_plane;
         g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
         g.ref32 = o.ref32; g.ldref32 = o.ldref32; g.ref16 = o.ref16; g.ldref16 = o.ldref16;
@@ -764,8 +767,8 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN)
         return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
     if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1 or 3");
-    if (pieces == 3 && o->mode != KURBM_MODE_VISIBLE_BERNOULLI)
-        return fail(KURBM_ERR_ARG, "the x3 path covers MODE_VISIBLE_BERNOULLI only (real-valued negative visibles: use kurbm_cd_step)");
+    if (pieces == 3 && o->mode != KURBM_MODE_VISIBLE_BERNOULLI && env_int("KURBM_X3_SEGMENTS", 0))
+        return fail(KURBM_ERR_ARG, "KURBM_X3_SEGMENTS covers MODE_VISIBLE_BERNOULLI only");
     if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
     if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
     if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
@@ -781,6 +784,8 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     const int noise_v = gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI;
     const uint32_t base = o->chain * 64u;
     const bool need_w = (which & 1) || o->delta_out;
+    // x3 with Gaussian visibles: v_t / v_neg are real-valued, so they travel as three pieces like real-valued data
+    const int vn_pieces = (pieces == 3 && gauss) ? 3 : 1;
     int e;
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
@@ -813,9 +818,9 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         r = make_rng(o->seed, o->row0, base + 2u * t - 1u, o->step);      // v_t ~ p(v | h_{t-1})   rbm.py:121-123
         if (KURBM_STAGE(2)) {
             HalfOutB ho;
-            ho.out = w.v2b; ho.ldo = w.Lv;
+            ho.out = w.v2b; ho.ldo = w.Lv; ho.out_pieces = vn_pieces; ho.out_plane = w.planeV;
             if (last) {
-                ho.outT = w.v2bT; ho.ldoT = w.Lb;
+                ho.outT = w.v2bT; ho.ldoT = w.Lb; ho.outT_pieces = vn_pieces; ho.outT_plane = w.planeVT;
                 ho.out_f32 = o->v_chain; ho.ldo32 = ldv;
                 ho.ref32 = v_batch; ho.ldref32 = ldv;
                 ho.grid_m_out = &gm_v;
@@ -831,7 +836,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             r = make_rng(o->seed, o->row0, base + 2u * t, o->step);
             HalfOutB ho;
             ho.out = w.h2b; ho.ldo = w.Lh;
-            if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, 1, 0, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
+            if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
             h_cur = w.h2b;
         }
     }
@@ -842,12 +847,12 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         ho.ref16 = w.hb; ho.ldref16 = w.Lh;
         ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.grid_m_out = &gm_h;
         if (pb) { ho.colpart = w.part_h + (size_t)2 * ceil_div(rows, 128) * w.ldh32; ho.colsign = -1.f; }
-        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, 1, 0, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st))) return e;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st))) return e;
     }
 
     // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
     // segments: (piece of v_pos) x h_pos, then v_neg x (piece of h_neg), negated
-    const int nseg_st = pieces == 3 ? v_pieces + 1 : 2;
+    const int nseg_st = pieces == 3 ? v_pieces + vn_pieces : 2;
     const OuterPlanB plf = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, nseg_st, pieces == 3);
     const int Mr = m_hi - m_lo;                         // visible rows of this call (all of them unless only == 7)
     const bool sub = (Mr != p->n_vis);
@@ -861,14 +866,14 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         GemmArgsB g;
         memset(&g, 0, sizeof g);
         g.A0 = w.vbT + (size_t)m_lo * w.Lb; g.a_plane0 = w.planeVT; g.B0 = w.hbT;
-        g.A1 = w.v2bT + (size_t)m_lo * w.Lb; g.B1 = w.hnT; g.b_plane1 = w.planeHT;
+        g.A1 = w.v2bT + (size_t)m_lo * w.Lb; g.a_plane1 = w.planeVT; g.B1 = w.hnT; g.b_plane1 = w.planeHT;
         g.lda = w.Lb; g.ldb = w.Lb;
         g.M = Mr; g.N = p->n_hid; g.K = w.Kb;
         g.grid_m = pl.gm; g.grid_n = pl.gn;
         g.slab = w.slab; g.slab_stride = slab_stride; g.ld_slab = pl.ld_slab;
         if (pb) {   // (piece of v_pos) x h_pos, then v_neg x (all pieces of h_neg), walked segment-fastest
             g.nseg = pb_codes(v_pieces, 1, 0u, &g.seg_codes, 0);
-            g.nseg = pb_codes(1, 3, 1u, &g.seg_codes, g.nseg);
+            g.nseg = pb_codes(vn_pieces, 3, 1u, &g.seg_codes, g.nseg);
             g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
             g.m_fastest = env_int("KURBM_X3_STATS_MFAST", 0);
             g.cfg = env_int("KURBM_X3_BN", 128) == 64 ? 1 : 0;

@@ -146,6 +146,8 @@ struct GemmArgsB {
     RngArgs rng;
     uint16_t* out;        // bf16 [M][ldo]   value plane (sample, or prob when noise = NONE); nullable
     int ldo;
+    int out_pieces;       // k_gemm_pb: 1 = the plane is 0/1 (one exact piece); 3 = real-valued, hi / mid / lo, out_plane apart
+    size_t out_plane;
     int ldo_cols;         // columns the row planes cover: ldo when `out` is set (pads are zeroed), else N
     uint16_t* outT;       // bf16 [N][ldoT]  the same plane transposed; nullable
     int ldoT;

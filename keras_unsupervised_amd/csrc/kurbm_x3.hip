@@ -381,8 +381,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
             }
         }
         __syncthreads();
-        // keep the MFMA waves' epilogue barriers company
-        if (EPI == EPI_SLAB || g.out) __syncthreads();
+        // keep the MFMA waves' epilogue barriers company: one per patch write, one between the pieces of a plane
+        if (EPI == EPI_SLAB) __syncthreads();
+        else if (g.out) {
+            const int nb = (g.out_pieces == 3) ? 5 : 1;
+            for (int q = 0; q < nb; ++q) __syncthreads();
+        }
         return;
     }
     Regs r0, r1;   // (never touched by the MFMA waves of the WS build: they stage nothing)
@@ -464,6 +468,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
                 for (int mi = 0; mi < TM; ++mi) {
                     const int rowb = rowq + mi * 16;
                     const uint32_t (&w)[4] = draws[(NOISE != NOISE_NONE) ? ni * TM + mi : 0];
+                    uint32_t w2[4] = {0u, 0u, 0u, 0u};
+                    if (NOISE == NOISE_GAUSSIAN) {
+                        const uint64_t grow = g.rng.row0 + (uint64_t)rowb;
+                        philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), g.rng.stream_id | 0x80000000u, g.rng.step,
+                                      g.rng.seed_lo, g.rng.seed_hi, w2);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x = acc[mi][ni][r] + bias;
@@ -472,7 +482,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
                         else if (ACT == ACT_RELU) p = fmaxf(x, 0.f);
                         else p = x;
                         const float ua = (NOISE != NOISE_NONE) ? u32_to_unit(w[r]) : 0.f;
-                        xv[mi][ni][r] = (NOISE == NOISE_BERNOULLI) ? ((ua < p) ? 1.0f : 0.0f) : p;
+                        if (NOISE == NOISE_GAUSSIAN)   // N(p, 1) by Box-Muller from the site's two planes (oracle/philox.py normal())
+                            xv[mi][ni][r] = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * u32_to_unit(w2[r]));
+                        else
+                            xv[mi][ni][r] = (NOISE == NOISE_BERNOULLI) ? ((ua < p) ? 1.0f : 0.0f) : p;
                         if (NOISE != NOISE_NONE && g.side && col_ok && rowb + r < g.M) {   // test planes
                             if (g.prob_f32) g.prob_f32[(size_t)(rowb + r) * g.ldo32 + col] = p;
                             if (g.out_u) g.out_u[(size_t)(rowb + r) * g.ldo32 + col] = ua;
@@ -558,36 +571,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
     //     then whole rows leave as 16-byte chunks.  Columns past N (k padding of the next GEMM) are zeros.
     if (g.out) {
         const int odd = l15 & 1;
+        const int npc = (g.out_pieces == 3) ? 3 : 1;     // a real-valued plane leaves as its three exact pieces
+        for (int j = 0; j < npc; ++j) {
+            if (j > 0) __syncthreads();                   // the previous piece has left the patch
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const bool col_ok = colb + ni * 16 < g.N;
+            for (int ni = 0; ni < TN; ++ni) {
+                const bool col_ok = colb + ni * 16 < g.N;
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
+                for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float mine = col_ok ? (odd ? xv[mi][ni][2 * h + 1] : xv[mi][ni][2 * h]) : 0.f;
-                    const float send = col_ok ? (odd ? xv[mi][ni][2 * h] : xv[mi][ni][2 * h + 1]) : 0.f;
-                    const float recv = pair_swap(send);
-                    const uint32_t pk = odd ? pack_bf16x2(recv, mine) : pack_bf16x2(mine, recv);
-                    *reinterpret_cast<uint32_t*>(smem + (wm * WM + mi * 16 + slot * 4 + 2 * h + odd) * PROW16 +
-                                                 2 * (wn * WN + ni * 16 + (l15 & ~1))) = pk;
-                }
-        }
-#ifdef KURBM_STAMPS
-        KURBM_STAMP(te[2]);
-#endif
-        __syncthreads();
-#ifdef KURBM_STAMPS
-        KURBM_STAMP(te[3]);
-#endif
-        constexpr int CH = BN / 8;   // 16-B chunks per row
+                    for (int h = 0; h < 2; ++h) {
+                        const float mine = col_ok ? (odd ? xv[mi][ni][2 * h + 1] : xv[mi][ni][2 * h]) : 0.f;
+                        const float send = col_ok ? (odd ? xv[mi][ni][2 * h] : xv[mi][ni][2 * h + 1]) : 0.f;
+                        const float recv = pair_swap(send);
+                        const uint32_t pk = odd ? pack_bf16x2(recv, mine) : pack_bf16x2(mine, recv);
+                        *reinterpret_cast<uint32_t*>(smem + (wm * WM + mi * 16 + slot * 4 + 2 * h + odd) * PROW16 +
+                                                     2 * (wn * WN + ni * 16 + (l15 & ~1))) = pk;
+                    }
+            }
+            if (j + 1 < npc) {   // residual of the piece just written: exact in fp32
 #pragma unroll
-        for (int j = 0; j < BM * CH / NT; ++j) {
-            const int q = j * NT + tid, row = q / CH, c = q % CH;
-            const int gr = m0 + row, gc = n0 + 8 * c;
-            if (gr < g.M && gc < g.ldo_cols)
-                *reinterpret_cast<u32x4*>(g.out + (size_t)gr * g.ldo + gc) =
-                    *reinterpret_cast<const u32x4*>(smem + row * PROW16 + 16 * c);
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xv[mi][ni][r] -= bf16_bits_to_f32(f32_to_bf16_bits(xv[mi][ni][r]));
+            }
+            __syncthreads();
+            constexpr int CH = BN / 8;   // 16-B chunks per row
+            uint16_t* plane = g.out + (size_t)j * g.out_plane;
+#pragma unroll
+            for (int q8 = 0; q8 < BM * CH / NT; ++q8) {
+                const int q = q8 * NT + tid, row = q / CH, c = q % CH;
+                const int gr = m0 + row, gc = n0 + 8 * c;
+                if (gr < g.M && gc < g.ldo_cols)
+                    *reinterpret_cast<u32x4*>(plane + (size_t)gr * g.ldo + gc) =
+                        *reinterpret_cast<const u32x4*>(smem + row * PROW16 + 16 * c);
+            }
         }
     }
     KURBM_STAMP(ts[4]);
@@ -633,6 +653,7 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     }
     KURBM_PB(EPI_HALFSTEP, NOISE_NONE)
     KURBM_PB(EPI_HALFSTEP, NOISE_BERNOULLI)
+    KURBM_PB(EPI_HALFSTEP, NOISE_GAUSSIAN)
     KURBM_PB(EPI_SLAB, NOISE_NONE)
 #undef KURBM_PB
     return hipErrorInvalidValue;

@@ -58,15 +58,13 @@ class RBM(object):
         self.cd_k = int(opt("cd_k", 1))
         self.persistent = bool(opt("persistent", False))
         # how the matrix products of fit() run (extension; storage, accumulation and results are fp32 in all):
-        #   'fp32'  fp32 MFMA               'x3'  fp32 values as exact bf16 triples on the bf16 MFMA (Bernoulli mode)
+        #   'fp32'  fp32 MFMA               'x3'  fp32 values as exact bf16 triples on the bf16 MFMA
         #   'bf16'  operands ROUNDED to bf16 (reduced precision, BASELINE.json config 5)
-        #   'auto'  (default) 'x3' for MODE_VISIBLE_BERNOULLI at batch sizes >= 1024, else 'fp32' (whose
+        #   'auto'  (default) 'x3' at batch sizes >= 1024, else 'fp32' (whose
         #           whole-epoch call serves small batches better)
         self.compute_dtype = str(opt("compute_dtype", "auto"))
         if self.compute_dtype not in ("fp32", "x3", "bf16", "auto"):
             raise ValueError("compute_dtype must be 'fp32', 'x3', 'bf16' or 'auto'")
-        if self.compute_dtype == "x3" and mode != MODE_VISIBLE_BERNOULLI:
-            raise ValueError("compute_dtype='x3' covers MODE_VISIBLE_BERNOULLI only (use 'auto' or 'fp32')")
         self.list_returns = bool(kwargs.pop("ku_compat_list_returns", True))
         self._device_arg = kwargs.pop("device", None)
         self._init_weights = kwargs.pop("weights", None)
@@ -281,8 +279,7 @@ class RBM(object):
 
     def _compute(self):
         if self.compute_dtype == "auto":
-            big = int(self.hps["batch_size"]) >= 1024
-            return "x3" if (self.mode == MODE_VISIBLE_BERNOULLI and big) else "fp32"
+            return "x3" if int(self.hps["batch_size"]) >= 1024 else "fp32"
         return self.compute_dtype
 
     def _update_local(self, Vd, lo, rows, lr, step):

@@ -647,10 +647,6 @@ def test_x3_cd_step_vs_oracle(gpu_device, cfg):
     assert np.max(np.abs(Wn - (W + np.float32(0.05) * dW))) <= 1e-5
     out = e.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=3)
     assert np.max(np.abs(out["prob"].to_numpy() - O.hidden_prob(v, Wn, bhn))) <= TOL
-    # Gaussian visibles are outside the x3 path: the library says so instead of computing something else
-    from keras_unsupervised_amd._lib import KurbmError
-    with pytest.raises(KurbmError):
-        e.cd_step(vd, B, 0, 0.05, 77, 9, mode=O.MODE_VISIBLE_GAUSSIAN, compute="x3")
 
 
 def test_x3_full_size_properties(gpu_device):
@@ -792,3 +788,36 @@ def test_x3_transform_surface(gpu_device):
     assert (Hb != h_ref).sum() <= 8
     Va, Vb = a.inv_transform(Ha)[0], b.inv_transform(Ha)[0]
     assert (Va != Vb).sum() <= 8
+
+
+@pytest.mark.parametrize("cfg", [dict(B=30, nv=52, nh=44, k=1), dict(B=200, nv=300, nh=140, k=2),
+                                 dict(B=130, nv=96, nh=260, k=1, pcd=True), dict(B=512, nv=784, nh=256, k=1)])
+def test_x3_gaussian_visibles_vs_oracle(gpu_device, cfg):
+    """MODE_VISIBLE_GAUSSIAN on the x3 path: the negative visibles are real-valued and travel as three exact pieces
+    (row-major for the next half step, transposed for the statistics).  Same oracle, same bar as the fp32 MFMA
+    Gaussian test (5e-4: Box-Muller's log / cos in fp32)."""
+    B, nv, nh, k = cfg["B"], cfg["nv"], cfg["nh"], cfg["k"]
+    mode = O.MODE_VISIBLE_GAUSSIAN
+    W, b_h, b_v = synthetic_params(nv, nh, seed=1400 + B)
+    v = synthetic_real(B, nv, seed=1401 + B)
+    chain0 = synthetic_real(B, nv, seed=1402 + B) if cfg.get("pcd") else None
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(v, gpu_device)
+    cd = _dm(chain0, gpu_device) if chain0 is not None else None
+    d1 = _gpu_cd_delta(e, vd, B, 0.01, 77, 9, k=k, mode=mode, v_chain=cd, compute="x3")
+    _, _, _, ch, (dW_ref, dbh_ref, dbv_ref) = O.cd_step_fused(W, b_h, b_v, v, 0.01, 77, 9, k=k, mode=mode, v_chain=chain0)
+    dW, dbh, dbv = _split(d1, nv, nh)
+    assert rel_err(dW, dW_ref) <= 5e-4 and rel_err(dbh, dbh_ref) <= 5e-4 and rel_err(dbv, dbv_ref) <= 5e-4
+    if cd is not None:
+        assert np.max(np.abs(cd.to_numpy() - ch["v_neg"])) <= 5e-4
+        cd = _dm(chain0, gpu_device)
+    d2 = _gpu_cd_delta(e, vd, B, 0.01, 77, 9, k=k, mode=mode, v_chain=cd, compute="x3")
+    assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    # against the fp32 MFMA kernels on the same counters
+    d32 = _gpu_cd_delta(e, vd, B, 0.01, 77, 9, k=k, mode=mode, v_chain=_dm(chain0, gpu_device) if chain0 is not None else None)
+    assert rel_err(d1[: nv * nh], d32[: nv * nh]) <= 5e-4
+    # half step hook: h -> v with N(loc, 1) noise
+    h = synthetic_binary(B, nh, seed=1403 + B, p=0.5)
+    out = e.half_step_bf16("hv", _dm(h, gpu_device), B, 2, 2, 3, 1, 1, pieces=3)
+    loc, z, v1 = O.sample_visible(h, W, b_v, O.Rng(3, 1), 1, mode)
+    assert np.max(np.abs(out["prob"].to_numpy() - loc)) <= TOL and np.max(np.abs(out["sample"].to_numpy() - v1)) <= 5e-4
