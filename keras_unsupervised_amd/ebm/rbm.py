@@ -157,8 +157,8 @@ class RBM(object):
         return [out] if as_list else out
 
     def _half(self, direction, x, act, noise, stream_id):
-        # large Bernoulli-mode inputs (a whole data set between DBN layers) go through the x3 kernels too
-        if self.mode == MODE_VISIBLE_BERNOULLI and self.compute_dtype in ("auto", "x3") and x.rows >= 1024:
+        # large inputs (a whole data set between DBN layers) go through the x3 kernels too
+        if self.compute_dtype in ("auto", "x3") and x.rows >= 1024:
             out = self._dev.half_step_bf16(direction, x, x.rows, act, noise, self.seed, stream_id, self._call_count, pieces=3,
                                            want_prob=False, want_u=False)
         else:

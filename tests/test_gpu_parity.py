@@ -788,6 +788,15 @@ def test_x3_transform_surface(gpu_device):
     assert (Hb != h_ref).sum() <= 8
     Va, Vb = a.inv_transform(Ha)[0], b.inv_transform(Ha)[0]
     assert (Va != Vb).sum() <= 8
+    # Gaussian visibles: relu-threshold hidden draws of real-valued data, N(loc, 1) visibles
+    from keras_unsupervised_amd.ebm import MODE_VISIBLE_GAUSSIAN
+    Vr = synthetic_real(N, nv, seed=1302)
+    a = RBM({"batch_size": 64, "epochs": 1, "lr": 0.01}, nh, mode=MODE_VISIBLE_GAUSSIAN, seed=3, weights=W0, compute_dtype="fp32")
+    b = RBM({"batch_size": 64, "epochs": 1, "lr": 0.01}, nh, mode=MODE_VISIBLE_GAUSSIAN, seed=3, weights=W0)
+    Ha, Hb = a.transform(Vr)[0], b.transform(Vr)[0]
+    assert (Ha != Hb).sum() <= 8
+    Va, Vb = a.inv_transform(Ha)[0], b.inv_transform(Ha)[0]
+    assert np.max(np.abs(Va - Vb)) <= 5e-4
 
 
 @pytest.mark.parametrize("cfg", [dict(B=30, nv=52, nh=44, k=1), dict(B=200, nv=300, nh=140, k=2),
