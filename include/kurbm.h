@@ -259,6 +259,12 @@ int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, 
                            int which, int stage, void* workspace, size_t workspace_bytes,
                            kurbm_stream_t stream);
 
+/* kurbm_free_energy on the x3 path (rbm.py:73-76): workspace >= the bf16 pieces of v + one float per row and
+ * 128-column tile (kurbm_x3_workspace_bytes of the same rows is enough). */
+int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v,
+                         int v_pieces, int rows, int ldv, float* F, void* workspace, size_t workspace_bytes,
+                         kurbm_stream_t stream);
+
 /* kurbm_cd_epoch on the x3 path: every batch of an epoch in one call (fused updates; returns the number of steps). */
 int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* V,
                       int v_pieces, int n_rows, int ldv, int batch_size, const kurbm_cd_opts* opts,

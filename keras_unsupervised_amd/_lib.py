@@ -67,6 +67,7 @@ SIGNATURES = {
     "kurbm_x3_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "kurbm_cd_step_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _vp, _sz, _vp]),
     "kurbm_cd_step_x3_stage": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _i, _vp, _sz, _vp]),
+    "kurbm_free_energy_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "kurbm_cd_epoch_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _i, _OP, _vp, _sz, _vp]),
     "kurbm_cd_chain_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _vp, _sz, _vp]),
     "kurbm_x3_stats_rows": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _i, _vp, _sz, _vp]),

@@ -990,6 +990,46 @@ int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, 
                        stage);
 }
 
+int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v, int v_pieces,
+                         int rows, int ldv, float* F, void* workspace, size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx || !F) return fail(KURBM_ERR_ARG, "null argument");
+    if (int e = check_params(p)) return e;
+    if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
+    if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1 or 3");
+    if (bad_matrix(v, ldv, p->n_vis)) return fail(KURBM_ERR_ARG, "v: null, misaligned, ld %% 4 != 0 or ld < n_vis");
+    if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, 3);
+    if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small");
+    // workspace: the bf16 pieces of v [Kb][Lp], then the row partials [column tiles][rows]
+    const int Lp = ld_pad(m.Kv), Kb = round_up(rows, 128);
+    const size_t plane = (size_t)Kb * Lp;
+    const size_t a_bytes = align_up(v_pieces * plane * 2);
+    GemmArgsB g;
+    memset(&g, 0, sizeof g);
+    g.grid_m = ceil_div(rows, 128); g.grid_n = ceil_div(p->n_hid, 128);
+    g.ld_rowpart = round_up(rows, 4);
+    const size_t need = a_bytes + (size_t)g.grid_n * g.ld_rowpart * 4;
+    if (need > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    uint16_t* Ab = static_cast<uint16_t*>(workspace);
+    HIP_TRY(launch_f32_to_bf16(v, rows, p->n_vis, ldv, Ab, Lp, Kb, nullptr, 0, 0, v_pieces, plane, 0, nullptr, 0, st));
+    g.A0 = Ab; g.lda = Lp; g.a_plane0 = plane;
+    g.B0 = m.Wtb; g.ldb = m.ldWt; g.b_plane0 = m.planeWt;
+    g.M = rows; g.N = p->n_hid; g.K = m.Kv;
+    g.nseg = pb_codes(v_pieces, 3, 0u, &g.seg_codes, 0);
+    g.nkt = g.K / 64; g.inv_nkt = inv_of(g.nkt);
+    g.kt_total = g.nseg * g.nkt; g.kt_per_split = g.kt_total; g.nsplit = 1;
+    g.m_fastest = 1;
+    g.bias = p->b_h;
+    g.rowpart = reinterpret_cast<float*>(static_cast<char*>(workspace) + a_bytes);
+    HIP_TRY(launch_gemm_pb(EPI_SOFTPLUS, g, st));
+    FinishArgs f;
+    f.v = v; f.b_v = p->b_v; f.rowpart = g.rowpart; f.F = F;
+    f.rows = rows; f.n_vis = p->n_vis; f.ldv = ldv; f.ncol_tiles = g.grid_n; f.ld_rowpart = g.ld_rowpart;
+    HIP_TRY(launch_free_energy_finish(f, st));
+    return KURBM_OK;
+}
+
 int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* V,
                       int v_pieces, int n_rows, int ldv, int batch_size, const kurbm_cd_opts* opts, void* workspace,
                       size_t workspace_bytes, kurbm_stream_t stream) {

@@ -168,6 +168,9 @@ struct GemmArgsB {
     float* slab;
     size_t slab_stride;
     int ld_slab;
+    // softplus epilogue (k_gemm_pb, free energy): rowpart[bn][row] = sum over the tile's columns of softplus(x + bias)
+    float* rowpart;
+    int ld_rowpart;
     // diagnostic build only (KURBM_STAMPS): 8 x u64 per workgroup (k_gemm_pb)
     unsigned long long* stamps;
 };

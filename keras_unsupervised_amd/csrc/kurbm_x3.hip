@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
     static_assert((BM * CPR) % NTS == 0 && (BN * CPR) % NTS == 0, "whole chunks per lane");
     constexpr int PROW16 = 2 * BN + 16;   // bf16 patch row (bytes)
     constexpr int PROW32 = 4 * BN + 16;   // fp32 patch row (bytes)
-    constexpr int PATCH_BYTES = BM * (EPI == EPI_SLAB ? PROW32 : PROW16);
+    constexpr int PATCH_BYTES = (EPI == EPI_SOFTPLUS) ? WAVES_N * BM * 4 : BM * (EPI == EPI_SLAB ? PROW32 : PROW16);
     constexpr int SMEM_BYTES = (2 * STAGE > PATCH_BYTES) ? 2 * STAGE : PATCH_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
         }
         __syncthreads();
         // keep the MFMA waves' epilogue barriers company: one per patch write, one between the pieces of a plane
-        if (EPI == EPI_SLAB) __syncthreads();
+        if (EPI == EPI_SLAB || EPI == EPI_SOFTPLUS) __syncthreads();
         else if (g.out) {
             const int nb = (g.out_pieces == 3) ? 5 : 1;
             for (int q = 0; q < nb; ++q) __syncthreads();
@@ -445,6 +445,47 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
                 const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * PROW32 + 16 * c);
                 *reinterpret_cast<f32x4*>(slab + (size_t)gr * g.ld_slab + gc) = v;
             }
+        }
+        KURBM_STAMP_OUT();
+        return;
+    }
+
+    // ---------------- epilogue: row sums of softplus(x + b) over the tile's columns (free energy, rbm.py:73-75) ----
+    if (EPI == EPI_SOFTPLUS) {
+        float rsum[TM][4];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rsum[mi][r] = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = n0 + wn * WN + ni * 16 + l15;
+            const bool cok = col < g.N;
+            const float bias = cok ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (cok) rsum[mi][r] += softplusf(acc[mi][ni][r] + bias);
+        }
+        float* red = reinterpret_cast<float*>(smem);   // [WAVES_N][BM]
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = rsum[mi][r];
+                t += __shfl_xor(t, 1);
+                t += __shfl_xor(t, 2);
+                t += __shfl_xor(t, 4);
+                t += __shfl_xor(t, 8);
+                if (l15 == 0) red[wn * BM + wm * WM + mi * 16 + slot * 4 + r] = t;
+            }
+        __syncthreads();
+        if (tid < BM) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < WAVES_N; ++i) t += red[i * BM + tid];
+            if (m0 + tid < g.M) g.rowpart[(size_t)bn * g.ld_rowpart + m0 + tid] = t;
         }
         KURBM_STAMP_OUT();
         return;
@@ -655,6 +696,7 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     KURBM_PB(EPI_HALFSTEP, NOISE_BERNOULLI)
     KURBM_PB(EPI_HALFSTEP, NOISE_GAUSSIAN)
     KURBM_PB(EPI_SLAB, NOISE_NONE)
+    KURBM_PB(EPI_SOFTPLUS, NOISE_NONE)
 #undef KURBM_PB
     return hipErrorInvalidValue;
 }

@@ -344,6 +344,10 @@ class DeviceRBM:
             else:
                 check(self.lib.kurbm_half_step_bf16(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), d,
                                                     x.ptr(row_start), rows, x.ld, *tail))
+            if noise == NOISE_BERNOULLI and out["sample"] is not None:
+                out["sample"].bf16_exact = True        # 0/1: one bf16 piece, no need to look
+            elif noise == NOISE_GAUSSIAN and out["sample"] is not None:
+                out["sample"].bf16_exact = False
         return out
 
     def apply_delta(self, lr, which=WHICH_ALL, delta=None, compute=None):
@@ -362,10 +366,18 @@ class DeviceRBM:
                                              int(which), self._stream()))
         self._weights_written()
 
-    def free_energy(self, v, rows, row_start=0):
+    def free_energy(self, v, rows, row_start=0, compute=None):
+        """F(v) per row (rbm.py:73-76).  compute='x3': the v.W product on the bf16 pieces (fp32-equivalent)."""
         with torch.cuda.device(self.device):
-            ws = self.workspace(rows)
             F = torch.empty(rows, dtype=torch.float32, device=self.device)
+            if compute == "x3":
+                vp = self.v_pieces(v)
+                mir, ws = self.mirror(3), self.workspace_bf16(rows, 1, 3, vp)
+                check(self.lib.kurbm_free_energy_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                                    v.ptr(row_start), vp, rows, v.ld, F.data_ptr(), ws.data_ptr(),
+                                                    ws.numel(), self._stream()))
+                return F
+            ws = self.workspace(rows)
             check(self.lib.kurbm_free_energy(self.ctx.handle, C.byref(self.params), v.ptr(row_start), rows, v.ld,
                                              F.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return F

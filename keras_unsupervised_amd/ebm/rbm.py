@@ -158,13 +158,17 @@ class RBM(object):
 
     def _half(self, direction, x, act, noise, stream_id):
         # large inputs (a whole data set between DBN layers) go through the x3 kernels too
-        if self.compute_dtype in ("auto", "x3") and x.rows >= 1024:
+        if self._large(x.rows):
             out = self._dev.half_step_bf16(direction, x, x.rows, act, noise, self.seed, stream_id, self._call_count, pieces=3,
                                            want_prob=False, want_u=False)
         else:
             out = self._dev.half_step(direction, x, x.rows, 0, act, noise, self.seed, stream_id, self._call_count)
         self._call_count += 1
         return out["sample"]
+
+    def _large(self, rows):
+        """Inference-side calls of at least 1024 rows use the x3 kernels (as training does from that batch size on)."""
+        return self.compute_dtype in ("auto", "x3") and rows >= 1024
 
     def _sample_hidden(self, x):
         act, noise = hidden_site(self.mode)
@@ -202,7 +206,7 @@ class RBM(object):
         n_cols = _unwrap(v).cols if isinstance(_unwrap(v), DeviceMatrix) else _unwrap(v).shape[1]
         self._ensure_built(n_cols)
         x, kind = self._as_device(v)
-        F = self._dev.free_energy(x, x.rows)
+        F = self._dev.free_energy(x, x.rows, compute="x3" if self._large(x.rows) else None)
         if kind in ("device", "torch"):
             return [F] if (self.list_returns and kind != "device") else F
         F = F.cpu().numpy()
@@ -215,10 +219,19 @@ class RBM(object):
     def _score(self, Vd, lo, rows, step):
         """mean |F(v) - F(v')| with v' a fresh one-step reconstruction (rbm.py:225-233)."""
         d = self._dev
-        fe = d.free_energy(Vd, rows, lo)
         act_h, noise_h = hidden_site(self.mode)
         act_v, noise_v = visible_site(self.mode)
         base = CHAIN_SCORE * CHAIN_STRIDE
+        if self._large(rows):
+            # same draws, the products on the bf16 pieces
+            fe = d.free_energy(Vd, rows, lo, compute="x3")
+            h = d.half_step_bf16("vh", Vd, rows, act_h, noise_h, self.seed, base + 0, step, pieces=3, row_start=lo,
+                                 want_prob=False, want_u=False)["sample"]
+            v1 = d.half_step_bf16("hv", h, rows, act_v, noise_v, self.seed, base + 1, step, pieces=3,
+                                  want_prob=False, want_u=False)["sample"]
+            fe_p = d.free_energy(v1, rows, 0, compute="x3")
+            return float((fe - fe_p).abs().mean().item())
+        fe = d.free_energy(Vd, rows, lo)
         h = d.half_step("vh", Vd, rows, lo, act_h, noise_h, self.seed, base + 0, step)["sample"]
         v1 = d.half_step("hv", h, rows, 0, act_v, noise_v, self.seed, base + 1, step)["sample"]
         fe_p = d.free_energy(v1, rows, 0)

@@ -830,3 +830,49 @@ def test_x3_gaussian_visibles_vs_oracle(gpu_device, cfg):
     out = e.half_step_bf16("hv", _dm(h, gpu_device), B, 2, 2, 3, 1, 1, pieces=3)
     loc, z, v1 = O.sample_visible(h, W, b_v, O.Rng(3, 1), 1, mode)
     assert np.max(np.abs(out["prob"].to_numpy() - loc)) <= TOL and np.max(np.abs(out["sample"].to_numpy() - v1)) <= 5e-4
+
+
+@pytest.mark.parametrize("shape", [(6, 64, 48), (150, 300, 200), (1024, 784, 1024), (1100, 130, 257)])
+def test_x3_free_energy_vs_oracle(gpu_device, shape):
+    """F(v) with the v.W product on the bf16 pieces (kurbm_free_energy_x3): same bar as the fp32 MFMA kernel, for 0/1
+    rows (one piece) and real-valued rows (three pieces), incl. a row large enough to overflow a literal softplus."""
+    B, nv, nh = shape
+    W, b_h, b_v = synthetic_params(nv, nh, seed=1500 + B)
+    e = _engine(W, b_h, b_v, gpu_device)
+    args64 = [a.astype(np.float64) for a in (W, b_h, b_v)]
+    for v in (synthetic_binary(B, nv, seed=1501 + B, p=0.4), synthetic_real(B, nv, seed=1502 + B)):
+        if v.max() > 1.0:
+            v[B - 1] *= 4000.0
+        vd = _dm(v, gpu_device)
+        F = e.free_energy(vd, B, compute="x3").cpu().numpy()
+        F32 = e.free_energy(vd, B).cpu().numpy()
+        ref = O.free_energy(v.astype(np.float64), *args64)
+        assert np.all(np.isfinite(F))
+        assert rel_err(F, ref) <= TOL
+        assert rel_err(F, F32) <= TOL
+    # a row window of a larger matrix
+    v = synthetic_real(B + 70, nv, seed=1503 + B)
+    F = e.free_energy(_dm(v, gpu_device), B, 64, compute="x3").cpu().numpy()
+    assert rel_err(F, O.free_energy(v[64:64 + B].astype(np.float64), *args64)) <= TOL
+
+
+@pytest.mark.parametrize("mode_name", ["bernoulli", "gaussian"])
+def test_x3_score_matches_fp32_score(gpu_device, mode_name, capsys):
+    """fit(verbose=1) at batch >= 1024 scores on the x3 kernels: same draws as the fp32 MFMA scoring, so the printed
+    score agrees to the rounding of a mean of |F - F'| (borderline draws may flip a handful of units)."""
+    from keras_unsupervised_amd.ebm import MODE_VISIBLE_BERNOULLI, MODE_VISIBLE_GAUSSIAN, RBM
+    mode = MODE_VISIBLE_BERNOULLI if mode_name == "bernoulli" else MODE_VISIBLE_GAUSSIAN
+    nv, nh, N = 96, 80, 2048
+    W0 = synthetic_params(nv, nh, seed=1600)
+    V = synthetic_binary(N, nv, seed=1601, p=0.3) if mode_name == "bernoulli" else synthetic_real(N, nv, seed=1602)
+    hps = {"batch_size": 1024, "epochs": 1, "lr": 0.01}
+    a = RBM(hps, nh, mode=mode, seed=5, weights=W0, compute_dtype="fp32")
+    b = RBM(hps, nh, mode=mode, seed=5, weights=W0)
+    a.fit(V, verbose=1)
+    b.fit(V, verbose=1)
+    capsys.readouterr()
+    assert len(a.last_scores) == len(b.last_scores) == 2
+    for sa, sb in zip(a.last_scores, b.last_scores):
+        assert abs(sa - sb) <= 1e-2 * max(1.0, abs(sa)), (sa, sb)
+    Fa, Fb = a.cal_free_energy(V)[0], b.cal_free_energy(V)[0]
+    assert rel_err(Fb, Fa) <= 5 * TOL      # the two fits differ by fp32 rounding of the updates
