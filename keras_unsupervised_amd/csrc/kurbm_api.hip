@@ -660,7 +660,12 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip), 128 x 128 tiles
         g.nseg = pb_codes(a_pieces, 3, 0u, &g.seg_codes, 0);
         g.cfg = env_int("KURBM_X3_BN", 128) == 64 ? 1 : 0;     // 1: 128 x 64 tiles, 256 threads, two workgroups per CU
-        g.grid_m = ceil_div(rows, 128); g.grid_n = ceil_div(g.N, g.cfg ? 64 : 128);
+        // 2: 256 x 64 tiles (fewer bytes per k-tile).  Whole 256-row tiles only: the bias partial rows are laid out
+        // per 64 rows, two per 128-row tile, and an even number of those is what both tilings agree on
+        const int tall = env_int("KURBM_X3_TALL", -1);
+        if (!g.cfg && ceil_div(rows, 128) % 2 == 0 &&
+            (tall == 1 || (tall < 0 && (rows / 256) * ceil_div(g.N, 64) * 4 >= 3 * ctx->ncu))) g.cfg = 2;
+        g.grid_m = ceil_div(rows, g.cfg == 2 ? 256 : 128); g.grid_n = ceil_div(g.N, g.cfg ? 64 : 128);
         g.nkt = g.K / 64;
         g.inv_nkt = inv_of(g.nkt);
         g.kt_total = g.nseg * g.nkt; g.kt_per_split = g.kt_total; g.nsplit = 1;
@@ -676,7 +681,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         // row tiles fastest: an XCD's run of workgroups then shares ONE column tile, whose weight pieces
         // (the operand loaded straight into registers, one tile ahead) stay in that XCD's L2
         g.m_fastest = env_int("KURBM_X3_MFAST", 1);
-        if (o.grid_m_out) *o.grid_m_out = g.grid_m;
+        if (o.grid_m_out) *o.grid_m_out = ceil_div(rows, 128);   // (in 128-row units whatever the tile)
         HIP_TRY(launch_gemm_pb(EPI_HALFSTEP, g, st));
         return KURBM_OK;
     }

@@ -18,6 +18,7 @@
 // :121-134); bf16 is an extension of this build, absent from the reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -101,20 +102,20 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
 // ------------------------------------------------------------------------------------
 // slab reduction + parameter update + weight-piece mirror in ONE launch (x3 / bf16 steps)
 // ------------------------------------------------------------------------------------
-// Blocks [0, tiles): a 16 x 64 tile of W each -- sum the split-K slabs in index order (bit-reproducible), W += lr * dW
+// Blocks [0, tiles): a TR x 64 tile of W each (TR = 16 / 32 / 64) -- sum the split-K slabs in index order (bit-reproducible), W += lr * dW
 // (and / or emit dW), then write the NEW weights as bf16 pieces row-major (8-byte stores) and, through an LDS transpose,
 // transposed; the k padding of both mirrors is rewritten as zeros.  Remaining blocks: the bias column sums of
 // k_reduce_apply (kurbm_kernels.hip).  Replaces k_reduce_apply + k_f32_to_bf16 on the fp32 master (one launch, one
 // pass over W instead of three).
+template <int TR>
 __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int tiles_x, int tiles) {
-    constexpr int TR = 16;
     __shared__ float tile[TR][CVT + 1];
     const int t = threadIdx.x;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     if ((int)blockIdx.x < tiles) {
         const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
         const int q4 = (t & 15) * 4, rq = t >> 4;
-        const int r = by * TR + rq, c = bx * CVT + q4;
+        const int c = bx * CVT + q4;
         auto store3 = [&](uint16_t* dst, size_t plane, float v0, float v1, float v2, float v3) {
             float v[4] = {v0, v1, v2, v3};
             for (int j = 0; j < a.pieces; ++j) {
@@ -127,45 +128,56 @@ __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int ti
                 }
             }
         };
-        f32x4 w = {0.f, 0.f, 0.f, 0.f};
-        if (r < a.n_vis && c < a.n_hid) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            if (a.slab) {
-                const float* sp = a.slab + (size_t)r * a.ld_slab + c;    // ld_slab % 4 == 0: the group stays inside the row
-                int zz = 0;
-                for (; zz + 4 <= a.nslab; zz += 4) {
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 0) * a.slab_stride);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 1) * a.slab_stride);
-                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 2) * a.slab_stride);
-                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 3) * a.slab_stride);
-                    s += v0; s += v1; s += v2; s += v3;
+#pragma unroll
+        for (int j = 0; j < TR / 16; ++j) {
+            const int r = by * TR + rq + 16 * j;
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (r < a.n_vis && c < a.n_hid) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                if (a.slab) {
+                    const float* sp = a.slab + (size_t)r * a.ld_slab + c;    // ld_slab % 4 == 0: the group stays inside the row
+                    int zz = 0;
+                    for (; zz + 4 <= a.nslab; zz += 4) {
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 0) * a.slab_stride);
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 1) * a.slab_stride);
+                        const f32x4 v2 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 2) * a.slab_stride);
+                        const f32x4 v3 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 3) * a.slab_stride);
+                        s += v0; s += v1; s += v2; s += v3;
+                    }
+                    for (; zz < a.nslab; ++zz) s += *reinterpret_cast<const f32x4*>(sp + (size_t)zz * a.slab_stride);
                 }
-                for (; zz < a.nslab; ++zz) s += *reinterpret_cast<const f32x4*>(sp + (size_t)zz * a.slab_stride);
-            }
-            if (a.W) {
-                float* wp = a.W + (size_t)r * a.ldw + c;                  // ldw % 4 == 0
-                w = *reinterpret_cast<const f32x4*>(wp);
-                if (a.slab) w = w + s * a.lr;
+                if (a.W) {
+                    float* wp = a.W + (size_t)r * a.ldw + c;                  // ldw % 4 == 0
+                    w = *reinterpret_cast<const f32x4*>(wp);
+                    if (a.slab) w = w + s * a.lr;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (c + e >= a.n_hid) w[e] = 0.f;                     // the row padding stays zero
-                if (a.slab) *reinterpret_cast<f32x4*>(wp) = w;
-            }
-            if (a.delta_w) {
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e >= a.n_hid) w[e] = 0.f;                     // the row padding stays zero
+                    if (a.slab) *reinterpret_cast<f32x4*>(wp) = w;
+                }
+                if (a.delta_w) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (c + e < a.n_hid) a.delta_w[(size_t)r * a.n_hid + c + e] = s[e];
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < a.n_hid) a.delta_w[(size_t)r * a.n_hid + c + e] = s[e];
+                }
             }
+            tile[rq + 16 * j][q4 + 0] = w.x; tile[rq + 16 * j][q4 + 1] = w.y;
+            tile[rq + 16 * j][q4 + 2] = w.z; tile[rq + 16 * j][q4 + 3] = w.w;
+            if (a.Wb && r < a.n_vis && c < a.ldWb) store3(a.Wb + (size_t)r * a.ldWb + c, a.planeWb, w.x, w.y, w.z, w.w);
         }
-        tile[rq][q4 + 0] = w.x; tile[rq][q4 + 1] = w.y; tile[rq][q4 + 2] = w.z; tile[rq][q4 + 3] = w.w;
-        if (a.Wb && r < a.n_vis && c < a.ldWb) store3(a.Wb + (size_t)r * a.ldWb + c, a.planeWb, w.x, w.y, w.z, w.w);
         __syncthreads();
         if (a.Wtb) {
-            const int rr4 = (t & 3) * 4, cq = t >> 2;       // 4 lanes x 4 rows down a column, 64 columns
-            const int cc = bx * CVT + cq, rr = by * TR + rr4;
-            if (cc < a.n_hid && rr < a.ldWtb)
-                store3(a.Wtb + (size_t)cc * a.ldWtb + rr, a.planeWtb, tile[rr4 + 0][cq], tile[rr4 + 1][cq], tile[rr4 + 2][cq],
-                       tile[rr4 + 3][cq]);
+            // TR / 4 lanes x 4 rows down a column of the tile (a run of 2 TR bytes per column), 1024 / TR columns per pass
+            constexpr int LPC = TR / 4, CPP = 256 / LPC;
+            const int rr4 = (t % LPC) * 4, cq = t / LPC;
+            const int rr = by * TR + rr4;
+#pragma unroll
+            for (int j = 0; j < CVT / CPP; ++j) {
+                const int cl = cq + CPP * j, cc = bx * CVT + cl;
+                if (cc < a.n_hid && rr < a.ldWtb)
+                    store3(a.Wtb + (size_t)cc * a.ldWtb + rr, a.planeWtb, tile[rr4 + 0][cl], tile[rr4 + 1][cl], tile[rr4 + 2][cl],
+                           tile[rr4 + 3][cl]);
+            }
         }
         return;
     }
@@ -656,9 +668,16 @@ hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st) {
     int r_ext = a.n_vis, c_ext = a.n_hid;
     if (a.Wb && a.ldWb > c_ext) c_ext = a.ldWb;
     if (a.Wtb && a.ldWtb > r_ext) r_ext = a.ldWtb;
-    const int tiles_x = (c_ext + CVT - 1) / CVT, tiles_y = (r_ext + 15) / 16;
     const int nb = (a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis) + 255) / 256;
-    hipLaunchKernelGGL(k_reduce_apply_split, dim3(tiles_x * tiles_y + nb), dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y);
+    const int tiles_x = (c_ext + CVT - 1) / CVT;
+    // taller tiles = longer runs in the transposed mirror (2 TR bytes per column) but fewer workgroups
+    static const int forced = getenv("KURBM_REDUCE_TR") ? atoi(getenv("KURBM_REDUCE_TR")) : 0;
+    int tr = forced ? forced : (tiles_x * ((r_ext + 31) / 32) >= 384 ? 32 : 16);
+    const int tiles_y = (r_ext + tr - 1) / tr;
+    const dim3 grid(tiles_x * tiles_y + nb);
+    if (tr == 64) hipLaunchKernelGGL(k_reduce_apply_split<64>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y);
+    else if (tr == 32) hipLaunchKernelGGL(k_reduce_apply_split<32>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y);
+    else hipLaunchKernelGGL(k_reduce_apply_split<16>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y);
     return hipGetLastError();
 }
 

@@ -685,6 +685,18 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     g.side = (g.prob_f32 != nullptr) || (g.out_u != nullptr);
     const int nblk = g.grid_m * g.grid_n * g.nsplit;
     static const int ws = getenv("KURBM_X3_WS") ? atoi(getenv("KURBM_X3_WS")) : 1;
+    // cfg 2: 256 x 64 tiles for the half steps (A tile 32 KB + three 8-KB pieces of B = 56 KB per k-tile instead of 64 KB
+    // for the same MFMAs: the k loop moves with the bytes a CU takes in)
+#define KURBM_PB_TALL(NZ)                                                                            \
+    if (epi == EPI_HALFSTEP && g.cfg == 2 && g.noise == NZ) {                                        \
+        hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, 3, EPI_HALFSTEP, NZ, true>), dim3(nblk), dim3(768), 0, st, g); \
+        return hipGetLastError();                                                                    \
+    }
+    KURBM_PB_TALL(NOISE_NONE)
+    KURBM_PB_TALL(NOISE_BERNOULLI)
+    KURBM_PB_TALL(NOISE_GAUSSIAN)
+#undef KURBM_PB_TALL
+    if (g.cfg == 2) return hipErrorInvalidValue;
 #define KURBM_PB(E, NZ)                                                                              \
     if (epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) {                                          \
         if (g.cfg == 1) hipLaunchKernelGGL((k_gemm_pb<128, 64, 2, 2, 64, 3, E, NZ>), dim3(nblk), dim3(256), 0, st, g); \
