@@ -665,7 +665,9 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         const int tall = env_int("KURBM_X3_TALL", -1);
         if (!g.cfg && ceil_div(rows, 128) % 2 == 0 &&
             (tall == 1 || (tall < 0 && (rows / 256) * ceil_div(g.N, 64) * 4 >= 3 * ctx->ncu))) g.cfg = 2;
-        g.grid_m = ceil_div(rows, g.cfg == 2 ? 256 : 128); g.grid_n = ceil_div(g.N, g.cfg ? 64 : 128);
+        // (64-column tiles: a row-major plane is the next GEMM's A operand, k-padded to 128 -- cover the padded row)
+        g.grid_m = ceil_div(rows, g.cfg == 2 ? 256 : 128);
+        g.grid_n = g.cfg ? ceil_div(o.out ? round_up(g.N, 128) : g.N, 64) : ceil_div(g.N, 128);
         g.nkt = g.K / 64;
         g.inv_nkt = inv_of(g.nkt);
         g.kt_total = g.nseg * g.nkt; g.kt_per_split = g.kt_total; g.nsplit = 1;

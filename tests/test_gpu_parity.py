@@ -876,3 +876,27 @@ def test_x3_score_matches_fp32_score(gpu_device, mode_name, capsys):
         assert abs(sa - sb) <= 1e-2 * max(1.0, abs(sa)), (sa, sb)
     Fa, Fb = a.cal_free_energy(V)[0], b.cal_free_energy(V)[0]
     assert rel_err(Fb, Fa) <= 5 * TOL      # the two fits differ by fp32 rounding of the updates
+
+
+@pytest.mark.parametrize("cfg", [dict(B=4096, nv=784, nh=1024, gauss=False), dict(B=512, nv=784, nh=200, gauss=False),
+                                 dict(B=200, nv=300, nh=140, gauss=True), dict(B=2048, nv=200, nh=1000, gauss=True)])
+def test_x3_step_does_not_read_uninitialised_workspace(gpu_device, cfg):
+    """The C ABI promises nothing about the workspace's contents: a step on a workspace (and weight mirror) full of 0xFF
+    bytes (bf16 NaNs in every k padding the kernels do not write themselves) gives the bits a zeroed workspace gives."""
+    B, nv, nh = cfg["B"], cfg["nv"], cfg["nh"]
+    mode = O.MODE_VISIBLE_GAUSSIAN if cfg["gauss"] else O.MODE_VISIBLE_BERNOULLI
+    W, b_h, b_v = synthetic_params(nv, nh, seed=1700 + B)
+    v = synthetic_real(B, nv, seed=1701 + B) if cfg["gauss"] else synthetic_binary(B, nv, seed=1701 + B, p=0.3)
+    got = []
+    for fill in (0, 0xFF):
+        e = _engine(W, b_h, b_v, gpu_device)
+        vd = _dm(v, gpu_device)
+        e.workspace_bf16(B, 1, 3, e.v_pieces(vd)).fill_(fill)
+        e.mirror(3).fill_(fill)
+        e._mirrors[3][1] = True        # stale: the library rewrites it from W (pads included) before the step
+        e.cd_step(vd, B, 0, 1e-3, 9, 0, mode=mode, compute="x3")
+        e.cd_step(vd, B, 0, 1e-3, 9, 1, mode=mode, compute="x3")
+        got.append([x.copy() for x in e.get_weights()])
+    for a, b in zip(*got):
+        assert np.all(np.isfinite(b))
+        assert np.array_equal(a, b)
