@@ -900,3 +900,28 @@ def test_x3_step_does_not_read_uninitialised_workspace(gpu_device, cfg):
     for a, b in zip(*got):
         assert np.all(np.isfinite(b))
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(4096, 784, 1024), (200, 300, 140)])
+def test_step_does_not_read_uninitialised_workspace(gpu_device, compute, shape):
+    """Same promise on the fp32 MFMA path and the rounded-bf16 path: 0xFF-filled scratch gives the bits zeroed scratch gives."""
+    B, nv, nh = shape
+    W, b_h, b_v = synthetic_params(nv, nh, seed=1800 + B)
+    v = synthetic_binary(B, nv, seed=1801 + B, p=0.3)
+    got = []
+    for fill in (0, 0xFF):
+        e = _engine(W, b_h, b_v, gpu_device)
+        vd = _dm(v, gpu_device)
+        if compute == "fp32":
+            e.workspace(B).fill_(fill)
+        else:
+            e.workspace_bf16(B, 1, 1, 1).fill_(fill)
+            e.mirror(1).fill_(fill)
+            e._mirrors[1][1] = True
+        for step in range(2):
+            e.cd_step(vd, B, 0, 1e-3, 9, step, compute=compute)
+        got.append([x.copy() for x in e.get_weights()])
+    for a, b in zip(*got):
+        assert np.all(np.isfinite(b))
+        assert np.array_equal(a, b)
