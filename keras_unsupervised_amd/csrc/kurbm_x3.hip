@@ -190,6 +190,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
     // CU): the eight loads of a tile issued back to back by all eight waves stall the later waves for ~1000 cycles,
     // so the k loop issues one part per micro-step.
     auto fetch_part = [&](Regs& R, const TileRef& r, int part) __attribute__((always_inline)) {
+#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 1)
+        return;   // timing-only build: no global loads (the registers keep whatever they hold)
+#endif
         if (part == 0) {
 #pragma unroll
             for (int it = 0; it < NA; ++it)
@@ -211,6 +214,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
     auto park = [&](const Regs& R, int buf, const TileRef& r, int c0, int c1) __attribute__((always_inline)) {
         unsigned char* a = smem + buf * STAGE;
         unsigned char* b = a + A_BYTES;
+#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 2)
+        // timing-only build: no LDS writes; every load stays live and is waited for here
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c < c0 || c >= c1) continue;
+            if (c < NA) asm volatile("" :: "v"(R.a[c]));
+            else asm volatile("" :: "v"(R.b[(c - NA) / NB1][(c - NA) % NB1]));
+        }
+        return;
+#endif
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (c < c0 || c >= c1) continue;
