@@ -91,7 +91,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
     constexpr int PROW32 = 4 * BN + 16;   // fp32 patch row (bytes)
     constexpr int PATCH_BYTES = (EPI == EPI_SOFTPLUS) ? WAVES_N * BM * 4 : BM * (EPI == EPI_SLAB ? PROW32 : PROW16);
     constexpr int SMEM_BYTES = (2 * STAGE > PATCH_BYTES) ? 2 * STAGE : PATCH_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+    // WS: the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
+    // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
+    constexpr int NI_LDS = (WS && EPI == EPI_HALFSTEP && NOISE != NOISE_NONE) ? 1 : 0;
+    constexpr int DRAW_LDS_BYTES = NI_LDS * TM * NT * 16;
+    static_assert(SMEM_BYTES + DRAW_LDS_BYTES <= 160 * 1024, "LDS per workgroup");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES + DRAW_LDS_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -403,6 +408,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
         return;
     }
     Regs r0, r1;   // (never touched by the MFMA waves of the WS build: they stage nothing)
+    if constexpr (NI_LDS > 0) {
+        if (nt > 0) {
+#pragma unroll
+            for (int ni = 0; ni < NI_LDS; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const uint64_t grow = g.rng.row0 + (uint64_t)(m0 + wm * WM + slot * 4 + mi * 16);
+                    uint32_t w[4];
+                    philox4x32_10((uint32_t)(n0 + wn * WN + l15 + ni * 16), (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step,
+                                  g.rng.seed_lo, g.rng.seed_hi, w);
+                    *reinterpret_cast<u32x4*>(smem + SMEM_BYTES + ((ni * TM + mi) * NT + tid) * 16) = u32x4{w[0], w[1], w[2], w[3]};
+                }
+        }
+    }
     if (WS) __builtin_amdgcn_s_setprio(2);   // the MFMA waves go first wherever a loader wave competes for issue
     if (nt > 0) {
         TileRef rc = tile_of(t_begin), rn = tile_of(t_begin + 1);
@@ -510,8 +529,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
     asm volatile("" : "+v"(colb));   // opaque: keeps the epilogue's address arithmetic out of the k loop's registers
     const int rowq = m0 + wm * WM + slot * 4;
     {
-        draw_cols(nt > 0 ? DRAW_EARLY : 0, TN, false);
-        auto elementwise = [&](auto act_tag) __attribute__((always_inline)) {
+        if constexpr (NI_LDS > 0) {
+            if (nt > 0) {
+#pragma unroll
+                for (int ni = 0; ni < NI_LDS; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        const u32x4 w = *reinterpret_cast<const u32x4*>(smem + SMEM_BYTES + ((ni * TM + mi) * NT + tid) * 16);
+                        draws[ni * TM + mi][0] = w.x; draws[ni * TM + mi][1] = w.y;
+                        draws[ni * TM + mi][2] = w.z; draws[ni * TM + mi][3] = w.w;
+                    }
+            }
+            draw_cols(nt > 0 ? NI_LDS : 0, TN, false);
+        } else {
+            draw_cols(nt > 0 ? DRAW_EARLY : 0, TN, false);
+        }
+        // (SIDE = the fp32 test planes are wanted: a compile-time tag, because a per-element test of g.side, however
+        //  uniform, puts a branch between every two of the 32 sigmoids of a lane and serialises their latencies)
+        auto elementwise = [&](auto act_tag, auto side_tag) __attribute__((always_inline)) {
+            constexpr bool SIDE = decltype(side_tag)::value;
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
@@ -540,7 +576,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
                             xv[mi][ni][r] = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * u32_to_unit(w2[r]));
                         else
                             xv[mi][ni][r] = (NOISE == NOISE_BERNOULLI) ? ((ua < p) ? 1.0f : 0.0f) : p;
-                        if (NOISE != NOISE_NONE && g.side && col_ok && rowb + r < g.M) {   // test planes
+                        if (NOISE != NOISE_NONE && SIDE && col_ok && rowb + r < g.M) {   // test planes
                             if (g.prob_f32) g.prob_f32[(size_t)(rowb + r) * g.ldo32 + col] = p;
                             if (g.out_u) g.out_u[(size_t)(rowb + r) * g.ldo32 + col] = ua;
                         }
@@ -548,9 +584,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
                 }
             }
         };
-        if (g.act == ACT_SIGMOID) elementwise(std::integral_constant<int, ACT_SIGMOID>{});
-        else if (g.act == ACT_RELU) elementwise(std::integral_constant<int, ACT_RELU>{});
-        else elementwise(std::integral_constant<int, ACT_LINEAR>{});
+        const bool side = (NOISE != NOISE_NONE) && g.side;
+        if (!side) {
+            if (g.act == ACT_SIGMOID) elementwise(std::integral_constant<int, ACT_SIGMOID>{}, std::false_type{});
+            else if (g.act == ACT_RELU) elementwise(std::integral_constant<int, ACT_RELU>{}, std::false_type{});
+            else elementwise(std::integral_constant<int, ACT_LINEAR>{}, std::false_type{});
+        } else {
+            if (g.act == ACT_SIGMOID) elementwise(std::integral_constant<int, ACT_SIGMOID>{}, std::true_type{});
+            else if (g.act == ACT_RELU) elementwise(std::integral_constant<int, ACT_RELU>{}, std::true_type{});
+            else elementwise(std::integral_constant<int, ACT_LINEAR>{}, std::true_type{});
+        }
     }
     KURBM_STAMP(ts[3]);
 
