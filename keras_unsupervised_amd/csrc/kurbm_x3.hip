@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
     constexpr int SMEM_BYTES = (2 * STAGE > PATCH_BYTES) ? 2 * STAGE : PATCH_BYTES;
     // WS: the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
     // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
-    constexpr int NI_LDS = (WS && EPI == EPI_HALFSTEP && NOISE != NOISE_NONE) ? 1 : 0;
+    constexpr int NI_LDS = (WS && EPI == EPI_HALFSTEP && NOISE == NOISE_BERNOULLI) ? 1 : 0;
     constexpr int DRAW_LDS_BYTES = NI_LDS * TM * NT * 16;
     static_assert(SMEM_BYTES + DRAW_LDS_BYTES <= 160 * 1024, "LDS per workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES + DRAW_LDS_BYTES];
@@ -576,7 +576,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
                             xv[mi][ni][r] = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * u32_to_unit(w2[r]));
                         else
                             xv[mi][ni][r] = (NOISE == NOISE_BERNOULLI) ? ((ua < p) ? 1.0f : 0.0f) : p;
-                        if (NOISE != NOISE_NONE && SIDE && col_ok && rowb + r < g.M) {   // test planes
+                        // (Gaussian: the run-time test stays -- 32 Box-Muller chains in flight at once spill)
+                        if (NOISE != NOISE_NONE && (NOISE == NOISE_GAUSSIAN ? g.side : SIDE) && col_ok && rowb + r < g.M) {   // test planes
                             if (g.prob_f32) g.prob_f32[(size_t)(rowb + r) * g.ldo32 + col] = p;
                             if (g.out_u) g.out_u[(size_t)(rowb + r) * g.ldo32 + col] = ua;
                         }
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
                 }
             }
         };
-        const bool side = (NOISE != NOISE_NONE) && g.side;
+        const bool side = (NOISE == NOISE_BERNOULLI) && g.side;
         if (!side) {
             if (g.act == ACT_SIGMOID) elementwise(std::integral_constant<int, ACT_SIGMOID>{}, std::false_type{});
             else if (g.act == ACT_RELU) elementwise(std::integral_constant<int, ACT_RELU>{}, std::false_type{});
