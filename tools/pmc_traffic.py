@@ -26,6 +26,10 @@ for ws in ("", ", true"):      # plain and wave-specialised instantiations
     label[("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 1%s>" % ws, 224)] = "x3_half_step_hv_sample"
     label[("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 0%s>" % ws, 256)] = "x3_half_step_vh_prob"
     label[("k_gemm_pb<128, 128, 2, 4, 64, 3, 1, 0%s>" % ws, 224)] = "x3_stats_gemm"
+# half steps on 256 x 64 tiles (tall_ok)
+label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true>", 256)] = "x3_half_step_vh_sample"
+label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true>", 224)] = "x3_half_step_hv_sample"
+label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 0, true>", 256)] = "x3_half_step_vh_prob"
 out = {}
 for key in sorted(set(fetch) | set(write)):
     name = label.get(key)
