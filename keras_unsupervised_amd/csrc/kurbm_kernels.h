@@ -168,6 +168,10 @@ struct GemmArgsB {
     float* slab;
     size_t slab_stride;
     int ld_slab;
+    // k_gemm_pb: XCD-aware 2-D blocks (set by the launcher; xcd_r == 0: the linear order).  The 8 XCDs form a
+    // (8 / (xcd_r xcd_c)) x xcd_r x xcd_c grid over (k slices, row tiles, column tiles); each takes one block of it, so the A
+    // rows and B rows it pulls through its own L2 are a fraction of the matrix instead of all of one operand
+    int xcd_r, xcd_c;
     // softplus epilogue (k_gemm_pb, free energy): rowpart[bn][row] = sum over the tile's columns of softplus(x + bias)
     float* rowpart;
     int ld_rowpart;

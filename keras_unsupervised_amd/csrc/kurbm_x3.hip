@@ -124,15 +124,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
 
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
-    {   // XCD-aware bijective remap (see kurbm_kernels.hip)
-        const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    int z, bm, bn;
+    if (g.xcd_r) {
+        // workgroup i runs on XCD i % 8: XCD (xz, xr, xc) owns k slices [xz zl, +zl), row tiles [xr rl, +rl), column tiles [xc cl, +cl)
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int rc = g.xcd_r * g.xcd_c;
+        const int xz = xcd / rc, xr = (xcd - xz * rc) / g.xcd_c, xc = xcd - xz * rc - xr * g.xcd_c;
+        const int rl = g.grid_m / g.xcd_r, cl = g.grid_n / g.xcd_c, zl = g.nsplit / (8 / rc);
+        const int zi = idx / (rl * cl), t2 = idx - zi * (rl * cl);
+        const int ri = g.m_fastest ? t2 % rl : t2 / cl;
+        const int ci = g.m_fastest ? t2 / rl : t2 - ri * cl;
+        z = xz * zl + zi; bm = xr * rl + ri; bn = xc * cl + ci;
+    } else {
+        {   // XCD-aware bijective remap (see kurbm_kernels.hip)
+            const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+            bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        }
+        const int tiles_mn = g.grid_m * g.grid_n;
+        z = bid / tiles_mn;
+        const int tmn = bid - z * tiles_mn;
+        bm = g.m_fastest ? tmn % g.grid_m : tmn / g.grid_n;
+        bn = g.m_fastest ? tmn / g.grid_m : tmn - bm * g.grid_n;
     }
-    const int tiles_mn = g.grid_m * g.grid_n;
-    const int z = bid / tiles_mn;
-    const int tmn = bid - z * tiles_mn;
-    const int bm = g.m_fastest ? tmn % g.grid_m : tmn / g.grid_n;
-    const int bn = g.m_fastest ? tmn / g.grid_m : tmn - bm * g.grid_n;
     const int m0 = bm * BM, n0 = bn * BN;
 
     const int t_begin = z * g.kt_per_split;
@@ -741,6 +754,24 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     }
     g.side = (g.prob_f32 != nullptr) || (g.out_u != nullptr);
     const int nblk = g.grid_m * g.grid_n * g.nsplit;
+    {   // XCD blocks: the factorisation 8 = xz * xr * xc (xz | nsplit, xr | grid_m, xc | grid_n) with the fewest operand rows
+        // per XCD, weighted by the tiles a k-tile loads (one A tile per segment, npb B tiles)
+        g.xcd_r = g.xcd_c = 0;
+        static const int on = getenv("KURBM_X3_XCD2D") ? atoi(getenv("KURBM_X3_XCD2D")) : 1;
+        if (on && nblk % 8 == 0) {
+            int wa = 0, wb = 0;
+            for (int sgm = 0; sgm < g.nseg; ++sgm) { wa += 1; wb += (int)((g.seg_codes >> (5 * sgm + 2)) & 3u); }
+            const int bmr = (g.cfg == 2) ? 256 : 128, bnr = g.cfg ? 64 : 128;
+            long long best = -1;
+            for (int xz = 1; xz <= 8; xz *= 2)
+                for (int xr = 1; xr * xz <= 8; xr *= 2) {
+                    const int xc = 8 / (xz * xr);
+                    if (g.nsplit % xz || g.grid_m % xr || g.grid_n % xc) continue;
+                    const long long cost = (long long)(g.nsplit / xz) * ((long long)(g.grid_m / xr) * bmr * wa + (long long)(g.grid_n / xc) * bnr * wb);
+                    if (best < 0 || cost < best) { best = cost; g.xcd_r = xr; g.xcd_c = xc; }
+                }
+        }
+    }
     static const int ws = getenv("KURBM_X3_WS") ? atoi(getenv("KURBM_X3_WS")) : 1;
     // cfg 2: 256 x 64 tiles for the half steps (A tile 32 KB + three 8-KB pieces of B = 56 KB per k-tile instead of 64 KB
     // for the same MFMAs: the k loop moves with the bytes a CU takes in)
