@@ -265,7 +265,9 @@ int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
                          int v_pieces, int rows, int ldv, float* F, void* workspace, size_t workspace_bytes,
                          kurbm_stream_t stream);
 
-/* kurbm_cd_epoch on the x3 path: every batch of an epoch in one call (fused updates; returns the number of steps). */
+/* kurbm_cd_epoch on the x3 path: every batch of an epoch in one call (fused updates; returns the number of steps).
+ * All work is ordered on `stream`.  (KURBM_X3_PIPE=1, an experiment that is off by default: batch t+1 is converted on a
+ * side stream owned by the context, joined to `stream` by events, into the second set of v_pos planes of the workspace.) */
 int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* V,
                       int v_pieces, int n_rows, int ldv, int batch_size, const kurbm_cd_opts* opts,
                       void* workspace, size_t workspace_bytes, kurbm_stream_t stream);

@@ -22,6 +22,9 @@ struct kurbm_ctx {
     int force_cfg[3];   // per layout: KURBM_CFG_VH / KURBM_CFG_HV / KURBM_CFG_OUTER
     int force_split;    // KURBM_SPLIT
     int tile_major;     // KURBM_TILE_MAJOR (default 1): k-slices of a statistics tile share an XCD
+    // kurbm_cd_epoch_x3: batch t+1 is converted on a side stream while step t runs (created on first use)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr};
 };
 
 static int env_int(const char* name, int dflt) {
@@ -249,7 +252,15 @@ int kurbm_ctx_create(int device, kurbm_ctx** out) {
     return KURBM_OK;
 }
 
-void kurbm_ctx_destroy(kurbm_ctx* ctx) { delete ctx; }
+void kurbm_ctx_destroy(kurbm_ctx* ctx) {
+    if (!ctx) return;
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->ev_main[i]) (void)hipEventDestroy(ctx->ev_main[i]);
+        if (ctx->ev_side[i]) (void)hipEventDestroy(ctx->ev_side[i]);
+    }
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    delete ctx;
+}
 
 int kurbm_philox_uniform(kurbm_ctx* ctx, float* out, int rows, int cols, int ld, const kurbm_rng* rng,
                          kurbm_stream_t stream) {
@@ -539,6 +550,8 @@ static Mirror carve_mirror(void* base, int n_vis, int n_hid, int pieces) {
 struct WorkspaceB {
     uint16_t *vb, *vbT, *hb, *hbT, *v2b, *v2bT, *h2b, *hnT, *cb;
     float *part_h, *part_v, *slab, *tmp32;
+    uint16_t *vb_alt = nullptr, *vbT_alt = nullptr;   // x3: a second set of v_pos planes (the epoch call converts batch t+1
+    float* part_v_alt = nullptr;                      //     while step t runs); behind everything else
     int Kv, Kh, Kb, Lv, Lh, Lb, ldh32, ldv32, max_row_tiles;   // K*: k extents; L*: leading dimensions of the bf16 planes
     size_t planeV, planeVT, planeHT;   // distance between the pieces of v_pos (both images) and of h_neg^T
     size_t slab_stride, bytes;
@@ -612,6 +625,10 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.part_v = take32((size_t)(ceil_div(rows, 64) + 2 * w.max_row_tiles) * w.ldv32);
     w.slab = take32(w.slab_stride * pl.nsplit_bound);
     w.tmp32 = take32((size_t)rows * (w.ldh32 > w.ldv32 ? w.ldh32 : w.ldv32));       // fp32 plane for the test hook
+    if (pieces == 3) {
+        w.vb_alt = take16(v_pieces * w.planeV); w.vbT_alt = take16(v_pieces * w.planeVT);
+        w.part_v_alt = take32((size_t)(ceil_div(rows, 64) + 2 * w.max_row_tiles) * w.ldv32);
+    }
     w.bytes = off;
     return w;
 }
@@ -759,12 +776,14 @@ static int half_step_any(kurbm_ctx* ctx, int pieces, int in_pieces, const kurbm_
 
 static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                        const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace,
-                       size_t workspace_bytes, kurbm_stream_t stream, int only = -1, int m_lo = 0, int m_hi = -1) {
+                       size_t workspace_bytes, kurbm_stream_t stream, int only = -1, int m_lo = 0, int m_hi = -1, int vset = 0) {
     // `only` 0..6 (measurement hook kurbm_cd_step_x3_stage): launch just that stage of the sequence, on the planes a
     // previous complete step left in the workspace.  8: the chain alone (stages 0-3, kurbm_cd_chain_x3).  7: the
     // statistics of visible rows [m_lo, m_hi) alone (stages 4-5, kurbm_x3_stats_rows) -- the data-parallel step
     // all-reduces the first rows of dW while the rest is still being computed.
-#define KURBM_STAGE(n) (only < 0 || only == (n) || (only == 8 && (n) <= 3) || (only == 7 && ((n) == 4 || (n) == 5)))
+    // 9: everything but the conversion of v_pos (stage 0), which kurbm_cd_epoch_x3 ran ahead on its side stream into the
+    // v_pos planes `vset` (0 / 1).
+#define KURBM_STAGE(n) (only < 0 || only == (n) || (only == 8 && (n) <= 3) || (only == 7 && ((n) == 4 || (n) == 5)) || (only == 9 && (n) != 0))
     if (m_hi < 0) m_hi = p ? p->n_vis : 0;
     if (!ctx || !o) return fail(KURBM_ERR_ARG, "null argument");
     if (int e = check_params(p)) return e;
@@ -782,8 +801,12 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, pieces);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
-    const WorkspaceB w = carve_bf16(ctx, workspace, rows, p->n_vis, p->n_hid, pieces, v_pieces);
+    WorkspaceB w = carve_bf16(ctx, workspace, rows, p->n_vis, p->n_hid, pieces, v_pieces);
     if (w.bytes > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    if (vset) {
+        if (!w.vb_alt) return fail(KURBM_ERR_ARG, "no second set of v_pos planes on this path");
+        w.vb = w.vb_alt; w.vbT = w.vbT_alt; w.part_v = w.part_v_alt;
+    }
 
     const bool gauss = (o->mode == KURBM_MODE_VISIBLE_GAUSSIAN);
     const int act_h = gauss ? ACT_RELU : ACT_SIGMOID;
@@ -1044,12 +1067,42 @@ int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_
     if (n_rows < 0 || batch_size <= 0) return fail(KURBM_ERR_ARG, "bad row count / batch size");
     if (opts->delta_out || !opts->apply) return fail(KURBM_ERR_ARG, "kurbm_cd_epoch_x3 applies in place: apply = 1, delta_out = null");
     kurbm_cd_opts o = *opts;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // Pipelined: while step t runs on `stream`, batch t+1 is converted (fp32 -> bf16 pieces, both orientations, column
+    // sums) on a side stream into the other set of v_pos planes; it fits beside the launches that leave CUs idle.
+    // Full batches only (a remainder batch lays the workspace out differently), never for one-step epochs.
+    // OFF by default: measured SLOWER (fit at config 2: 155 -> 167-172 us per step, also with the side stream at the lowest
+    // priority) -- the conversion's workgroups take CU slots a GEMM workgroup (144 KB of LDS, all the registers) then waits for.
+    bool pipe = env_int("KURBM_X3_PIPE", 0) != 0 && n_rows >= 2 * batch_size;
+    if (pipe && !ctx->side) {
+        int least = 0, greatest = 0;   // lowest priority: the conversion fills idle CUs, never ahead of a GEMM's workgroups
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_main[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming));
+        }
+    }
     int steps = 0;
+    bool have_pre = false;   // this step's v_pos planes are already on their way (side stream)
     for (int lo = 0; lo < n_rows; lo += batch_size, ++steps) {
         const int rows = (n_rows - lo < batch_size) ? n_rows - lo : batch_size;
+        const int par = steps & 1;
+        const bool next_full = pipe && rows == batch_size && n_rows - (lo + batch_size) >= batch_size;
+        if (next_full) {
+            // the other set was last read by step t-1 (statistics GEMM, slab reduce): all of it is ahead of this event
+            HIP_TRY(hipEventRecord(ctx->ev_main[par], st));
+            HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_main[par], 0));
+            if (int e = cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, V + (size_t)(lo + batch_size) * ldv, rows, ldv, &o, 7,
+                                    workspace, workspace_bytes, ctx->side, 0, 0, -1, par ^ 1))
+                return e;
+            HIP_TRY(hipEventRecord(ctx->ev_side[par ^ 1], ctx->side));
+        }
+        if (have_pre) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side[par], 0));
         if (int e = cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, V + (size_t)lo * ldv, rows, ldv, &o, 7, workspace,
-                                workspace_bytes, stream))
+                                workspace_bytes, stream, have_pre ? 9 : -1, 0, -1, pipe ? par : 0))
             return e;
+        have_pre = next_full;
         ++o.step;
     }
     return steps;

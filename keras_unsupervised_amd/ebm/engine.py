@@ -294,8 +294,9 @@ class DeviceRBM:
                 self._weights_written(kept=3)
 
     def cd_epoch(self, v, n_rows, batch_size, lr, seed, step0, k=1, mode=MODE_VISIBLE_BERNOULLI, v_chain=None,
-                 compute="fp32"):
-        """All batches of one epoch in ONE library call (fused updates, no score); returns #steps."""
+                 compute="fp32", row_start=0):
+        """All batches of rows [row_start, row_start + n_rows) in ONE library call (fused updates, no score); returns #steps.
+        On the x3 path the library converts batch t+1 on a side stream while step t runs."""
         if compute == "x3":
             with torch.cuda.device(self.device):
                 vp = self.v_pieces(v)
@@ -305,7 +306,7 @@ class DeviceRBM:
                 mir, ws = self.mirror(3), self.workspace_bf16(rows, k, 3, vp)
                 opts = CdOpts(int(k), int(mode), float(lr), 1, None, v_chain.ptr() if v_chain is not None else None,
                               int(seed), 0, int(step0) & 0xFFFFFFFF, 0)
-                n = self.lib.kurbm_cd_epoch_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), v.ptr(), vp,
+                n = self.lib.kurbm_cd_epoch_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), v.ptr(row_start), vp,
                                                int(n_rows), v.ld, int(batch_size), C.byref(opts), ws.data_ptr(), ws.numel(),
                                                self._stream())
                 if n < 0:
@@ -316,7 +317,7 @@ class DeviceRBM:
             ws = self.workspace(min(batch_size, max(n_rows, 1)), k)
             opts = CdOpts(int(k), int(mode), float(lr), 1, None, v_chain.ptr() if v_chain is not None else None,
                           int(seed), 0, int(step0) & 0xFFFFFFFF, 0)
-            n = self.lib.kurbm_cd_epoch(self.ctx.handle, C.byref(self.params), v.ptr(), int(n_rows), v.ld,
+            n = self.lib.kurbm_cd_epoch(self.ctx.handle, C.byref(self.params), v.ptr(row_start), int(n_rows), v.ld,
                                         int(batch_size), C.byref(opts), ws.data_ptr(), ws.numel(), self._stream())
             if n < 0:
                 check(n)

@@ -484,16 +484,23 @@ def test_bf16_rbm_fit(gpu_device):
     assert not np.array_equal(a.rbm_weight, b.rbm_weight)
 
 
-def test_x3_epoch_call_equals_step_loop(gpu_device):
-    """kurbm_cd_epoch_x3 (one call per epoch) and the per-step host loop give bit-identical parameters."""
-    nv, nh = 72, 40
+@pytest.mark.parametrize("pipe", ["0", "1"])
+@pytest.mark.parametrize("shape", [(150, 64, 72, 40, 2), (1400, 256, 200, 136, 1), (512, 256, 784, 64, 1)])
+def test_x3_epoch_call_equals_step_loop(gpu_device, monkeypatch, pipe, shape):
+    """kurbm_cd_epoch_x3 (one call per epoch) and the per-step host loop give bit-identical parameters -- also with
+    KURBM_X3_PIPE=1, where batch t+1 is converted on a side stream into a second set of planes while step t runs
+    (two calls in a row: the second epoch starts on the planes the first one left)."""
+    N, bs, nv, nh, k = shape
+    monkeypatch.setenv("KURBM_X3_PIPE", pipe)
     W0 = synthetic_params(nv, nh, seed=700)
-    V = synthetic_binary(150, nv, seed=701, p=0.3)
+    V = synthetic_binary(N, nv, seed=701, p=0.3)
     a, b = _engine(*W0, gpu_device), _engine(*W0, gpu_device)
     vd = _dm(V, gpu_device)
-    assert a.cd_epoch(vd, 150, 64, 0.01, 9, 5, k=2, compute="x3") == 3
-    for i, (lo, hi) in enumerate(O.batch_slices(150, 64)):
-        b.cd_step(vd, hi - lo, lo, 0.01, 9, 5 + i, k=2, compute="x3")
+    nsteps = len(O.batch_slices(N, bs))
+    for epoch in range(2):
+        assert a.cd_epoch(vd, N, bs, 0.01, 9, 5 + epoch * nsteps, k=k, compute="x3") == nsteps
+        for i, (lo, hi) in enumerate(O.batch_slices(N, bs)):
+            b.cd_step(vd, hi - lo, lo, 0.01, 9, 5 + epoch * nsteps + i, k=k, compute="x3")
     for x, y in zip(a.get_weights(), b.get_weights()):
         assert np.array_equal(x, y)
 
