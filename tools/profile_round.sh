@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01k
+O=$R/gpurun_out/${1:-r01k}
 mkdir -p $O
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
