@@ -118,10 +118,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
 
+    pipe = dp.X3Pipeline(eng) if (args.compute == "x3" and dp.PRECONVERT and not dp.OVERLAP_ROW_RANGES) else None
+
     def step(i):
         lo = (i % n_batches) * BATCH
         if world == 1 and not force_dp:
             eng.cd_step(V, BATCH, lo, lr, seed, i, compute=args.compute)
+        elif pipe is not None:
+            # chain + statistics -> packed sums -> all-reduce (with the NEXT batch's conversion under it) -> apply
+            pipe.step(V, BATCH, lo, lr, seed, i, nxt=(((i + 1) % n_batches) * BATCH, BATCH), row0=rank * BATCH)
         else:
             if args.compute == "x3" and dp.OVERLAP_ROW_RANGES:
                 dp.x3_sums_overlapped(eng, V, BATCH, lo, lr, seed, i, row0=rank * BATCH)

@@ -253,6 +253,9 @@ int kurbm_cd_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t
  * step left in `workspace` (same arguments as that step).  stage: 0 v_pos -> bf16 pieces, 1 h_pos half
  * step, 2 v_neg half step(s), 3 h_neg half step, 4 statistics GEMM, 5 slab reduction + parameter
  * update + mirror refresh, 6 mirror refresh alone.  bench.py times the kernels of a step with it.
+ * Stages 0 and 9 (= everything but stage 0) also split a step in two for the data-parallel loop: the conversion of the
+ * NEXT batch (stage 0; it does not depend on the parameters) runs while the all-reduce of this step's sums is in flight,
+ * and the next step starts at stage 9 on the same `rows`.
  */
 int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                            const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts,

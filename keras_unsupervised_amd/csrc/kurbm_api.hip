@@ -1015,7 +1015,7 @@ int kurbm_cd_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t
 int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
                            int v_pieces, int rows, int ldv, const kurbm_cd_opts* o, int which, int stage, void* workspace,
                            size_t workspace_bytes, kurbm_stream_t stream) {
-    if (stage < 0 || stage > 6) return fail(KURBM_ERR_ARG, "stage must be in [0, 6]");
+    if ((stage < 0 || stage > 6) && stage != 9) return fail(KURBM_ERR_ARG, "stage must be in [0, 6], or 9");
     return cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, which, workspace, workspace_bytes, stream,
                        stage);
 }

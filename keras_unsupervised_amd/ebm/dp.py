@@ -19,6 +19,10 @@ import os
 # [384,784) take 25.6 + 33.9 us against 46.2 us in one piece, so hiding the first all-reduce (~30 us of an estimated
 # ~56 us at 8 GPUs) under the second range nets ~3 us, and the extra launches make the step host-bound.
 OVERLAP_ROW_RANGES = os.environ.get("KURBM_DP_OVERLAP", "0") == "1"
+# x3 data-parallel step: convert the next batch while this step's all-reduce is in flight (X3Pipeline).  OFF by default:
+# on one rank (1-rank RCCL group, nothing to hide under) the step got 10 us LONGER with the host well ahead of the GPU
+# (tools/dp_host_time.py: 150.6 -> 161.6 us), and the N > 1 case cannot be measured on the one-GPU boxes of this build.
+PRECONVERT = os.environ.get("KURBM_DP_PRECONVERT", "0") == "1"
 
 
 def world():
@@ -47,6 +51,34 @@ def allreduce_sum_(delta, async_op=False):
     if dist.is_available() and dist.is_initialized():
         return dist.all_reduce(delta, op=dist.ReduceOp.SUM, async_op=async_op)
     return None
+
+
+class X3Pipeline:
+    """The data-parallel x3 step with the NEXT batch's conversion (fp32 -> bf16 planes, both orientations, column sums;
+    independent of the parameters) enqueued while this step's all-reduce is in flight:
+
+        [convert t]  chain t, statistics t, packed sums   all-reduce t (RCCL stream)   apply t   chain t+1 ...
+                                                          convert t+1 (compute stream)
+
+    `nxt` = (row_start, rows) of the rows this rank takes next, or None.  Only batches of the same row count are
+    pre-converted (the workspace layout follows the row count)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.ready = None
+
+    def step(self, V, rows, lo, lr, seed, step, nxt=None, **kw):
+        eng = self.eng
+        part = "rest" if self.ready == (id(V), lo, rows) else None
+        eng.cd_step(V, rows, lo, lr, seed, step, apply=False, emit_delta=True, compute="x3", part=part, **kw)
+        work = allreduce_sum_(eng.delta_buffer(), async_op=True)
+        self.ready = None
+        if nxt is not None and nxt[1] == rows:
+            eng.cd_step(V, rows, nxt[0], lr, seed, step + 1, apply=False, emit_delta=True, compute="x3", part="convert", **kw)
+            self.ready = (id(V), nxt[0], rows)
+        if work is not None:
+            work.wait()
+        eng.apply_delta(lr, compute="x3")
 
 
 def packed_size(n_vis, n_hid):

@@ -218,11 +218,14 @@ class DeviceRBM:
 
     def cd_step(self, v, rows, row_start, lr, seed, step, k=1, mode=MODE_VISIBLE_BERNOULLI, chain=0,
                 which=WHICH_ALL, apply=True, emit_delta=False, v_chain=None, row0=0, v_chain_row=0, bf16=False,
-                compute=None):
+                compute=None, part=None):
         """One CD-k update on rows [row_start, row_start+rows) of DeviceMatrix v.
 
         compute: 'fp32' (fp32 MFMA), 'x3' (fp32 values as exact bf16 triples on the bf16 MFMA),
-        'bf16' (operands rounded to bf16)."""
+        'bf16' (operands rounded to bf16).
+        part (x3 only): 'convert' = only the conversion of these rows into the workspace's v_pos planes; 'rest' = the
+        step on planes a 'convert' of the same rows left there (dp.X3Pipeline: the conversion of the next batch runs
+        under the all-reduce of this one)."""
         compute = compute or ("bf16" if bf16 else "fp32")
         with torch.cuda.device(self.device):
             opts = CdOpts(int(k), int(mode), float(lr), 1 if apply else 0,
@@ -241,10 +244,16 @@ class DeviceRBM:
                 if v_chain is not None and vp == 1:
                     vp = self.v_pieces(v_chain)
                 mir, ws = self.mirror(3), self.workspace_bf16(rows, k, 3, vp)
-                check(self.lib.kurbm_cd_step_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
-                                                v.ptr(row_start), vp, rows, v.ld, C.byref(opts), int(which),
-                                                ws.data_ptr(), ws.numel(), self._stream()))
-                if apply and (which & 1):
+                if part is None:
+                    check(self.lib.kurbm_cd_step_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                                    v.ptr(row_start), vp, rows, v.ld, C.byref(opts), int(which),
+                                                    ws.data_ptr(), ws.numel(), self._stream()))
+                else:
+                    stage = {"convert": 0, "rest": 9}[part]
+                    check(self.lib.kurbm_cd_step_x3_stage(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                                          v.ptr(row_start), vp, rows, v.ld, C.byref(opts), int(which), stage,
+                                                          ws.data_ptr(), ws.numel(), self._stream()))
+                if apply and (which & 1) and part != "convert":
                     self._weights_written(kept=3)
             elif compute == "fp32":
                 ws = self.workspace(rows, k)
@@ -295,8 +304,7 @@ class DeviceRBM:
 
     def cd_epoch(self, v, n_rows, batch_size, lr, seed, step0, k=1, mode=MODE_VISIBLE_BERNOULLI, v_chain=None,
                  compute="fp32", row_start=0):
-        """All batches of rows [row_start, row_start + n_rows) in ONE library call (fused updates, no score); returns #steps.
-        On the x3 path the library converts batch t+1 on a side stream while step t runs."""
+        """All batches of rows [row_start, row_start + n_rows) in ONE library call (fused updates, no score); returns #steps."""
         if compute == "x3":
             with torch.cuda.device(self.device):
                 vp = self.v_pieces(v)

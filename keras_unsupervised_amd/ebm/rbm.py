@@ -282,7 +282,8 @@ class RBM(object):
                 if world == 1:
                     self._update_local(Vd, lo, rows, lr, step)
                 else:
-                    self._update_data_parallel(Vd, lo, rows, lr, step, rank, world)
+                    nxt = (hi, min(hi + bs, n) - hi) if i + 1 < num_step else None
+                    self._update_data_parallel(Vd, lo, rows, lr, step, rank, world, nxt)
                 self._update_count += 1
                 if verbose == 1:
                     score = self._score(Vd, lo, rows, step)
@@ -307,8 +308,9 @@ class RBM(object):
                 d.cd_step(Vd, rows, lo, lr, self.seed, step, k=1, mode=self.mode, chain=chain, which=which,
                           compute=self._compute())
 
-    def _update_data_parallel(self, Vd, lo, rows, lr, step, rank, world):
-        """Each rank: chain on its rows -> packed sums -> one all-reduce -> identical apply."""
+    def _update_data_parallel(self, Vd, lo, rows, lr, step, rank, world, nxt=None):
+        """Each rank: chain on its rows -> packed sums -> one all-reduce -> identical apply.
+        nxt = (row_start, rows) of the next batch: on the x3 path its conversion runs under this step's all-reduce."""
         if self.update_mode != "fused":
             raise ValueError("data-parallel training supports update_mode='fused' only")
         d = self._dev
@@ -318,6 +320,16 @@ class RBM(object):
             # chain, then dW in two row ranges: the first all-reduce overlaps the second range's GEMM
             dp.x3_sums_overlapped(d, Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, row0=s_lo,
                                   v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo)
+        elif s_hi > s_lo and self._compute() == "x3" and dp.PRECONVERT:
+            if getattr(self, "_dp_pipe", None) is None or self._dp_pipe.eng is not d:
+                self._dp_pipe = dp.X3Pipeline(d)
+            nxt_shard = None
+            if nxt is not None:
+                n_lo, n_hi = dp.shard_rows(nxt[1], world, rank)
+                nxt_shard = (nxt[0] + n_lo, n_hi - n_lo)
+            self._dp_pipe.step(Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, nxt=nxt_shard, k=self.cd_k, mode=self.mode,
+                               chain=CHAIN_W, row0=s_lo, v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo)
+            return
         else:
             if s_hi > s_lo:
                 d.cd_step(Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,

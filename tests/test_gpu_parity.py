@@ -932,3 +932,29 @@ def test_step_does_not_read_uninitialised_workspace(gpu_device, compute, shape):
     for a, b in zip(*got):
         assert np.all(np.isfinite(b))
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("cfg", [dict(B=256, nv=200, nh=136, k=1, mode="bernoulli"), dict(B=512, nv=784, nh=64, k=2, mode="gaussian")])
+def test_x3_dp_preconvert_equals_plain_sequence(gpu_device, cfg):
+    """dp.X3Pipeline (the next batch converted while this step's all-reduce is in flight; a step then starts at stage 9 on
+    the planes already in the workspace) leaves the bits of the plain sequence emit -> all-reduce -> apply.  Ragged tail:
+    the last batch has another row count and is not pre-converted."""
+    from keras_unsupervised_amd.ebm import dp
+    B, nv, nh, k = cfg["B"], cfg["nv"], cfg["nh"], cfg["k"]
+    mode = O.MODE_VISIBLE_GAUSSIAN if cfg["mode"] == "gaussian" else O.MODE_VISIBLE_BERNOULLI
+    N = 4 * B + 70
+    W0 = synthetic_params(nv, nh, seed=1900)
+    V = synthetic_real(N, nv, seed=1901) if cfg["mode"] == "gaussian" else synthetic_binary(N, nv, seed=1901, p=0.3)
+    a, b = _engine(*W0, gpu_device), _engine(*W0, gpu_device)
+    va, vb = _dm(V, gpu_device), _dm(V, gpu_device)
+    slices = O.batch_slices(N, B)
+    pipe = dp.X3Pipeline(a)
+    for epoch in range(2):
+        for i, (lo, hi) in enumerate(slices):
+            step = epoch * len(slices) + i
+            nxt = (slices[i + 1][0], slices[i + 1][1] - slices[i + 1][0]) if i + 1 < len(slices) else None
+            pipe.step(va, hi - lo, lo, 0.01, 9, step, nxt=nxt, k=k, mode=mode, row0=lo)
+            b.cd_step(vb, hi - lo, lo, 0.01, 9, step, k=k, mode=mode, apply=False, emit_delta=True, row0=lo, compute="x3")
+            b.apply_delta(0.01, compute="x3")
+    for x, y in zip(a.get_weights(), b.get_weights()):
+        assert np.array_equal(x, y)
