@@ -151,7 +151,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
     const int t_begin = z * g.kt_per_split;
     int t_end = t_begin + g.kt_per_split;
     if (t_end > g.kt_total) t_end = g.kt_total;
-    const int nt = t_end > t_begin ? t_end - t_begin : 0;
+    // (a half-step tile that lies wholly in the column padding of its row-major plane has nothing to multiply: it only
+    //  writes that plane's zeros)
+    const int nt = (t_end > t_begin && !(EPI == EPI_HALFSTEP && n0 >= g.N)) ? t_end - t_begin : 0;
 
     // Staging map: chunk q -> (row q / CPR, 16-B chunk q % CPR); rows outside the matrix are pointed at
     // row 0 (they only feed outputs that are never stored).  Loads are buffer loads: a per-lane BYTE
