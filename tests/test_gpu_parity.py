@@ -958,3 +958,31 @@ def test_x3_dp_preconvert_equals_plain_sequence(gpu_device, cfg):
             b.apply_delta(0.01, compute="x3")
     for x, y in zip(a.get_weights(), b.get_weights()):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("tall", ["0", "1"])
+@pytest.mark.parametrize("shape", [(256, 64, 64), (512, 100, 500), (1024, 784, 200), (768, 200, 136), (2048, 130, 1024),
+                                   (1300, 784, 257), (4096, 1024, 784)])
+def test_x3_half_steps_tile_configs(gpu_device, monkeypatch, tall, shape):
+    """The x3 half steps on forced 128 x 128 and forced 256 x 64 tiles (KURBM_X3_TALL; the tall kernels need an even number
+    of 128-row tiles and are skipped otherwise), with whatever XCD block factorisation the grid admits: probabilities and
+    draws against the oracle, row-major and transposed planes through a second half step on the output."""
+    B, nv, nh = shape
+    monkeypatch.setenv("KURBM_X3_TALL", tall)
+    W, b_h, b_v = synthetic_params(nv, nh, seed=2000 + B)
+    e = _engine(W, b_h, b_v, gpu_device)
+    rng = O.Rng(5, 3)
+    for v in (synthetic_binary(B, nv, seed=2001 + B, p=0.3), synthetic_real(B, nv, seed=2002 + B)):
+        out = e.half_step_bf16("vh", _dm(v, gpu_device), B, 0, 1, 5, 2, 3, pieces=3)
+        check_half_step(out, *O.sample_hidden(v, W, b_h, rng, 2))
+    h = synthetic_binary(B, nh, seed=2003 + B, p=0.5)
+    out = e.half_step_bf16("hv", _dm(h, gpu_device), B, 0, 1, 5, 3, 3, pieces=3)
+    check_half_step(out, *O.sample_visible(h, W, b_v, rng, 3))
+    # a whole step on the same tiles: updates within the fp32 bar of the fp32 MFMA path's (same draws; a borderline
+    # draw may flip a unit, which moves single entries of dW by lr * 1)
+    v = synthetic_binary(B, nv, seed=2004 + B, p=0.3)
+    a, b = _engine(W, b_h, b_v, gpu_device), _engine(W, b_h, b_v, gpu_device)
+    a.cd_step(_dm(v, gpu_device), B, 0, 1e-3, 11, 0, compute="x3")
+    b.cd_step(_dm(v, gpu_device), B, 0, 1e-3, 11, 0, compute="fp32")
+    dW = np.abs(a.get_weights()[0] - b.get_weights()[0])
+    assert np.mean(dW > 1e-6) < 1e-3 and np.all(np.isfinite(a.get_weights()[0]))
