@@ -3,23 +3,34 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): CD-1 Gibbs-steps/sec on a 784-visible x 1024-hidden RBM at batch 4096,
-fp32, synthetic binary data resident in HBM.  --compute picks how the matrix products run: "x3"
-(default: fp32 values carried as exact bf16 triples on the bf16 matrix cores, fp32 accumulate --
-results held to the fp32 oracle and the fp32 tolerances by tests/test_gpu_parity.py::test_x3_*) or
-"fp32" (fp32 MFMA).  Rank 0 times BOTH paths after the timed region and reports them under `paths`.  One "step" (the unit of `value`) = one full CD-1
-parameter update over 4096 rows: h_pos sample, v_neg sample, h_neg probabilities, dW / db_h / db_v
-applied (update_mode "fused").  With N > 1 every rank processes its own 4096 rows per step (weak
-scaling: global batch 4096 N, config 3 at N = 8), the packed [dW|db_h|db_v] sums are all-reduced
-over RCCL, and `value` counts N units per global step.
+Metric (BASELINE.json): CD-1 Gibbs-steps/sec on a 784-visible x 1024-hidden RBM at batch 4096, fp32 storage /
+accumulation / results, synthetic binary data resident in HBM.  One "step" (the unit of `value`) = one full CD-1
+parameter update over 4096 rows: h_pos sample, v_neg sample, h_neg probabilities, dW / db_h / db_v applied
+(update_mode "fused").  --compute picks how the matrix products run: "x3" (default: fp32 values carried as exact
+bf16 triples on the bf16 matrix cores -- held to the fp32 oracle and the fp32 tolerances by the tests) or "fp32"
+(fp32 MFMA); rank 0 times BOTH after the timed region and reports them under `paths`, next to the real-valued-data
+and Gaussian-mode (the reference's default) variants.
 
-The line also carries `roofline` (per-launch fp32-MFMA fraction of the dominant kernel, HIP-event
-timed on the launch stream) and `cpu_baseline` (the numpy oracle of the same step timed on this
-host's cores; rank 0, N = 1 only).
+Timing protocol: W untimed warm-up steps, then R blocks of exactly K steps, each bracketed by a barrier +
+torch.cuda.synchronize() on both sides (R = 1 when K >= 200, else max(5, ceil(200 / K))); the block time is the MAX
+over ranks.  `value` = N * K / median(block times); `value_first_block` is the first block alone (a cold GPU: the
+step time falls ~15 % over the first ~20 ms while the clocks ramp); `value_steady` is the median of R more blocks
+after 256 further untimed steps.  All three are on the line, labelled in config.timing.
+
+With N > 1 (one process per GPU, torch.distributed.run) every rank processes its own 4096 rows per step (weak scaling:
+global batch 4096 N, config 3 at N = 8) through kurbm_cd_step_x3_dp: the packed [dW|db_h|db_v] sums are all-reduced by
+RCCL inside libkurbm.so, in row ranges overlapped with the statistics GEMM.  torch.distributed (gloo) only carries the
+RCCL unique id and the max-over-ranks of the block times; the barriers are all-reduces on the RCCL communicator itself.
+`rccl_ranks` is ncclCommCount's answer.
+
+The line also carries `roofline` (dominant kernel, HIP-event timed on the launch stream, and the whole step) and
+`cpu_baseline` (oracle/cpu_baseline.py: the same op sequence on torch-CPU over all host cores; rank 0, N = 1 only).
 """
 import argparse
 import json
+import math
 import os
+import statistics
 import sys
 import time
 
@@ -34,9 +45,14 @@ if ROOT not in sys.path:
 N_VIS, N_HID, BATCH = 784, 1024, 4096
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CU x 256 flop/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16
-FLOP_HALF = 2.0 * BATCH * N_VIS * N_HID            # one half-step GEMM
-FLOP_OUTER = 4.0 * BATCH * N_VIS * N_HID           # statistics GEMM: k = 2 x batch
-FLOP_STEP = 3 * FLOP_HALF + FLOP_OUTER             # 10 B V H
+BVH2 = 2.0 * BATCH * N_VIS * N_HID                 # one GEMM unit: B x V x H multiply-adds
+FLOP_HALF = BVH2                                   # one half-step GEMM
+FLOP_OUTER = 2 * BVH2                              # statistics GEMM: k = 2 x batch
+FLOP_STEP = 3 * FLOP_HALF + FLOP_OUTER             # 10 B V H, the algorithmic work of a CD-1 step
+# bf16 GEMM units the x3 path EXECUTES per step (pieces): binary data 3+3+3 half steps, 1+3 statistics; real-valued data
+# 6+3+3 and 3+3; Gaussian visibles on real-valued data 6+3+(3+2+1) and 3+(3+2+1)
+X3_UNITS = {"binary": 13, "real": 18, "gaussian_real": 24}
+SETTLE_STEPS = 256
 
 
 def event_time_ms(fn, iters, warm=3):
@@ -53,27 +69,6 @@ def event_time_ms(fn, iters, warm=3):
     return t0.elapsed_time(t1) / iters
 
 
-def cpu_baseline():
-    """The oracle's fused CD-1 step (numpy + OpenBLAS) on the host cores, bounded sample."""
-    from oracle import rbm_oracle as O
-    from oracle.make_golden import synthetic_binary, synthetic_params
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    W, b_h, b_v = synthetic_params(N_VIS, N_HID, seed=1)
-    v = synthetic_binary(BATCH, N_VIS, seed=1234)
-    O.cd_step_fused(W, b_h, b_v, v, 1e-3 / BATCH, 42, 0)      # warm
-    n, t0 = 0, time.perf_counter()
-    while n < 5 or (time.perf_counter() - t0 < 10.0 and n < 40):
-        W, b_h, b_v, _, _ = O.cd_step_fused(W, b_h, b_v, v, 1e-3 / BATCH, 42, n + 1)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "steps/s", "cores": int(cores), "kind": "port",
-            "sample": "%d fused CD-1 steps of oracle/rbm_oracle.py (numpy sgemm + numpy Philox), 784x1024, B=4096" % n}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,17 +82,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                     "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
+                 "--master-port P bench.py --gpus %d ...  (WORLD_SIZE is %d)" % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only (unique id, max of times)
 
     from keras_unsupervised_amd.ebm import dp
-    from keras_unsupervised_amd.ebm.engine import DeviceMatrix, DeviceRBM
+    from keras_unsupervised_amd.ebm.engine import MODE_VISIBLE_GAUSSIAN, DeviceMatrix, DeviceRBM
 
     # synthetic workload, resident in HBM before the timed region
     g = np.random.default_rng(1)
@@ -106,77 +100,72 @@ def main():
     n_batches = 16
     u = eng.philox_uniform(n_batches * BATCH, N_VIS, 1234 + rank, 0x7004, 0)
     V = DeviceMatrix((u.t < 0.19).to(torch.float32).contiguous(), n_batches * BATCH, N_VIS, u.ld)
-    del u
     lr = 1e-3 / BATCH            # keeps the weights finite over long runs; throughput does not depend on lr
     seed = 42
 
-    # BENCH_FORCE_DP=1 runs the data-parallel sequence (emit delta, all-reduce, apply) even on one
-    # rank: a plumbing rehearsal of the N > 1 path on a single-GPU box
-    force_dp = os.environ.get("BENCH_FORCE_DP", "0") == "1"
-    if force_dp and world == 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-
-    pipe = dp.X3Pipeline(eng) if (args.compute == "x3" and dp.PRECONVERT and not dp.OVERLAP_ROW_RANGES) else None
+    # BENCH_FORCE_DP=1 runs the data-parallel step (1-rank RCCL communicator) on a single-GPU box: a rehearsal of the N > 1 path
+    use_dp = world > 1 or os.environ.get("BENCH_FORCE_DP", "0") == "1"
+    comm = dp.get_comm(device) if use_dp else None
+    rccl_ranks = comm.count() if comm is not None else None
+    if comm is not None:
+        assert rccl_ranks == world, "RCCL reports %d ranks, launched %d" % (rccl_ranks, world)
 
     def step(i):
         lo = (i % n_batches) * BATCH
-        if world == 1 and not force_dp:
+        if comm is None:
             eng.cd_step(V, BATCH, lo, lr, seed, i, compute=args.compute)
-        elif pipe is not None:
-            # chain + statistics -> packed sums -> all-reduce (with the NEXT batch's conversion under it) -> apply
-            pipe.step(V, BATCH, lo, lr, seed, i, nxt=(((i + 1) % n_batches) * BATCH, BATCH), row0=rank * BATCH)
         else:
-            if args.compute == "x3" and dp.OVERLAP_ROW_RANGES:
-                dp.x3_sums_overlapped(eng, V, BATCH, lo, lr, seed, i, row0=rank * BATCH)
-            else:
-                eng.cd_step(V, BATCH, lo, lr, seed, i, apply=False, emit_delta=True, row0=rank * BATCH, compute=args.compute)
-                dp.allreduce_sum_(eng.delta_buffer())
-            eng.apply_delta(lr, compute=args.compute)
+            eng.cd_step_dp(comm, V, BATCH, lo, lr, seed, i, row0=rank * BATCH, compute=args.compute)
 
-    # set-up, untimed and outside the W warm-up steps: every lazily created buffer (workspace, weight-piece mirror,
-    # exactness flag of the data) gets created, and the GPU reaches the clocks it holds under this load -- the kernel
-    # trace of a cold start shows the step time falling from 157 to 134 us over the first ~160 steps (20 ms)
-    # (profiles/r01_m_kernel_stats.csv's run).  Reported in config.setup_steps.
-    SETUP_STEPS = int(os.environ.get("BENCH_SETUP_STEPS", "256"))
-    for i in range(SETUP_STEPS):
-        step(i)
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def fence():
+        if comm is not None:
+            comm.barrier()       # device idle -> all-reduce on the RCCL communicator -> device idle
+        torch.cuda.synchronize()
+
+    counter = [0]
+
+    def timed_block(k):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(counter[0])
+            counter[0] += 1
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(args.warmup):
+        step(counter[0])
+        counter[0] += 1
+    repeats = 1 if args.steps >= 200 else max(5, math.ceil(200 / max(args.steps, 1)))
+    blocks = [timed_block(args.steps) for _ in range(repeats)]
+    for _ in range(SETTLE_STEPS):
+        step(counter[0])
+        counter[0] += 1
+    steady = [timed_block(args.steps) for _ in range(repeats)]
     assert bool(torch.isfinite(eng.W.t).all().item()), "weights diverged"
+    fence()          # every rank is past its last data-parallel step; from here on only rank 0 touches its GPU
 
     out = None
     if rank == 0:
+        elapsed = statistics.median(blocks)
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
-        # per-kernel durations (HIP events on the launch stream), each launched alone
+        rate = lambda dt: world * args.steps / dt
+        import ctypes as C
+        from keras_unsupervised_amd import _lib
+        # ---- per-kernel durations (HIP events on the launch stream), each launched alone --------------------------
         h_pos = eng.half_step("vh", V, BATCH, 0, 0, 1, seed, 0, 0)["sample"]
         v_neg = eng.half_step("hv", h_pos, BATCH, 0, 0, 1, seed, 1, 0)["sample"]
         h_neg = eng.half_step("vh", v_neg, BATCH, 0, 0, 0, seed, 0, 0, want_sample=False, want_prob=True)["prob"]
-        import ctypes as C
-        from keras_unsupervised_amd import _lib
         ws = eng.workspace(BATCH)
         rng = _lib.Rng(seed, 0, 0, 0)
         o_h = DeviceMatrix.zeros(BATCH, N_HID, device)
         o_v = DeviceMatrix.zeros(BATCH, N_VIS, device)
-        dW = torch.empty((N_VIS, N_HID), dtype=torch.float32, device=device)
         st = lambda: C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         lib, ctx, P = eng.lib, eng.ctx.handle, C.byref(eng.params)
         k_vh = lambda: _lib.check(lib.kurbm_half_step_vh(ctx, P, V.ptr(), BATCH, V.ld, 0, 1, C.byref(rng), o_h.ptr(), None, o_h.ld, st()))
@@ -184,18 +173,14 @@ def main():
         k_vhp = lambda: _lib.check(lib.kurbm_half_step_vh(ctx, P, v_neg.ptr(), BATCH, v_neg.ld, 0, 0, None, None, o_h.ptr(), o_h.ld, st()))
         k_out = lambda: _lib.check(lib.kurbm_outer_partial(ctx, V.ptr(), h_pos.ptr(), v_neg.ptr(), h_neg.ptr(), BATCH, N_VIS, N_HID,
                                                            V.ld, h_pos.ld, ws.data_ptr(), ws.numel(), st()))
-        k_outred = lambda: _lib.check(lib.kurbm_outer_delta(ctx, V.ptr(), h_pos.ptr(), v_neg.ptr(), h_neg.ptr(), BATCH, N_VIS, N_HID,
-                                                            V.ld, h_pos.ld, dW.data_ptr(), ws.data_ptr(), ws.numel(), st()))
         kern = {}
         for name, fn, flop in (("half_step_vh_sample", k_vh, FLOP_HALF), ("half_step_hv_sample", k_hv, FLOP_HALF),
-                               ("half_step_vh_prob", k_vhp, FLOP_HALF), ("outer_stats_gemm", k_out, FLOP_OUTER),
-                               ("outer_stats_gemm_plus_reduce", k_outred, FLOP_OUTER)):
+                               ("half_step_vh_prob", k_vhp, FLOP_HALF), ("outer_stats_gemm", k_out, FLOP_OUTER)):
             ms = event_time_ms(fn, 50)
             kern[name] = {"ms": ms, "tflops": flop / (ms * 1e-3) / 1e12, "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
         # the x3 launches, each alone, replayed on the planes of a complete x3 step (kurbm_cd_step_x3_stage)
         eng.cd_step(V, BATCH, 0, lr, seed, 0, compute="x3")
-        x3_exec = {"x3_half_step_vh_sample": 3 * FLOP_HALF, "x3_half_step_hv_sample": 3 * FLOP_HALF,
-                   "x3_half_step_vh_prob": 3 * FLOP_HALF, "x3_stats_gemm": 4 * FLOP_HALF}     # executed bf16 flop (pieces)
+        x3_units = {"x3_half_step_vh_sample": 3, "x3_half_step_hv_sample": 3, "x3_half_step_vh_prob": 3, "x3_stats_gemm": 4}
         x3_algo = {"x3_half_step_vh_sample": FLOP_HALF, "x3_half_step_hv_sample": FLOP_HALF,
                    "x3_half_step_vh_prob": FLOP_HALF, "x3_stats_gemm": FLOP_OUTER}
         kern_x3 = {}
@@ -203,45 +188,64 @@ def main():
                             ("x3_half_step_vh_prob", 3), ("x3_stats_gemm", 4), ("x3_reduce_apply_plus_mirror", 5)):
             ms = event_time_ms(lambda stage=stage: eng.cd_step_x3_stage(V, BATCH, 0, lr, seed, 0, stage), 50)
             kern_x3[name] = {"ms": ms}
-            if name in x3_exec:
-                kern_x3[name].update({"executed_bf16_tflops": x3_exec[name] / (ms * 1e-3) / 1e12,
-                                      "frac_of_bf16_peak": x3_exec[name] / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+            if name in x3_units:
+                ex = x3_units[name] * BVH2
+                kern_x3[name].update({"executed_bf16_tflops": ex / (ms * 1e-3) / 1e12,
+                                      "frac_of_bf16_peak": ex / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                                       "algorithmic_tflops": x3_algo[name] / (ms * 1e-3) / 1e12})
-        # both compute paths, same batch, HIP events (single GPU, local step)
-        paths = {}
-        for c in ("x3", "fp32"):
-            ms = event_time_ms(lambda c=c: eng.cd_step(V, BATCH, 0, lr, seed, 0, compute=c), 100, warm=10)
+        # ---- whole-step variants, same engine, HIP events (single GPU, local step) ---------------------------------
+        def path(fn, units=None):
+            ms = event_time_ms(fn, 100, warm=10)
             tf = FLOP_STEP / (ms * 1e-3) / 1e12
-            paths[c] = {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "algorithmic_tflops": tf,
-                        "frac_of_fp32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS}
-        traffic_all = {}
+            r = {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "algorithmic_tflops": tf}
+            if units is None:
+                r["frac_of_fp32_mfma_peak"] = tf / PEAK_F32_MFMA_TFLOPS
+            else:
+                r["executed_bf16_tflops"] = units * BVH2 / (ms * 1e-3) / 1e12
+                r["executed_frac_of_bf16_peak"] = r["executed_bf16_tflops"] / PEAK_BF16_MFMA_TFLOPS
+            return r
+        paths = {"x3": path(lambda: eng.cd_step(V, BATCH, 0, lr, seed, 0, compute="x3"), X3_UNITS["binary"]),
+                 "fp32": path(lambda: eng.cd_step(V, BATCH, 0, lr, seed, 0, compute="fp32"))}
+        # grey-level data (k / 255, not bf16-exact: the batch travels as three pieces), Bernoulli mode and the
+        # reference's default Gaussian-visible mode (rbm.py:22; relu thresholds, N(loc, 1) visibles)
+        ug = eng.philox_uniform(BATCH, N_VIS, 99, 0x7005, 0)
+        Vg = DeviceMatrix((torch.floor(ug.t * 256.0) / 255.0).contiguous(), BATCH, N_VIS, ug.ld)
+        paths["x3_real_valued"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, compute="x3"), X3_UNITS["real"])
+        paths["fp32_real_valued"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, compute="fp32"))
+        Wkeep = eng.get_weights()
+        paths["gaussian_default_mode"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, mode=MODE_VISIBLE_GAUSSIAN, compute="x3"),
+                                              X3_UNITS["gaussian_real"])
+        paths["gaussian_default_mode_fp32"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, mode=MODE_VISIBLE_GAUSSIAN, compute="fp32"))
+        eng.set_weights(*Wkeep)
+        traffic_all, traffic_file = {}, None
         try:
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
                 traffic_all.update(json.load(open(f)))      # later files win
+                traffic_file = os.path.relpath(f, ROOT)
         except Exception:
             traffic_all = {}
         if args.compute == "x3":
-            dom = max(x3_exec, key=lambda k: kern_x3[k]["ms"])
+            dom = max(x3_units, key=lambda k: kern_x3[k]["ms"])
             roofline = {"bound": "mfma", "kernel": dom, "achieved": kern_x3[dom]["executed_bf16_tflops"],
                         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": kern_x3[dom]["frac_of_bf16_peak"],
-                        "note": "executed bf16 MFMA flop (the pieces: 3 per half step, 1 + 3 for the statistics) against the dense "
-                                "bf16 peak; algorithmic fp32 flop/s of the same launch in kernels[...].algorithmic_tflops",
+                        "note": "EXECUTED bf16 MFMA flop of the launch (its pieces: 3 GEMM units per half step, 1 + 3 for the statistics; "
+                                "one unit = 2 B V H) against the dense bf16 peak, launch duration by HIP events in this run",
                         "traffic": traffic_all.get(dom, {}).get("hbm_bytes_per_launch"),
-                        "algorithmic": {"achieved": kern_x3[dom]["algorithmic_tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                                        "unit": "TFLOP/s", "frac": kern_x3[dom]["algorithmic_tflops"] / PEAK_F32_MFMA_TFLOPS,
-                                        "note": "SURVEY 8(d) algorithmic fp32 flop of this launch (4 B V H for the statistics, "
-                                                "2 B V H per half step) against the fp32 MFMA peak the north star names"},
+                        "traffic_source": "%s (rocprofv3 --pmc passes of an earlier run of this command; not measured in this run)" % traffic_file,
+                        "step": {"executed_bf16_tflops": X3_UNITS["binary"] * BVH2 / (ms_per_step * 1e-3) / 1e12 * world,
+                                 "frac": X3_UNITS["binary"] * BVH2 / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                                 "note": "all 13 bf16 GEMM units of a step over the timed step time, per GPU against the bf16 peak"},
                         "kernels": kern_x3, "kernels_fp32_path": kern}
         else:
-            dom = max((k for k in kern if k != "outer_stats_gemm_plus_reduce"), key=lambda k: kern[k]["ms"])
+            dom = max(kern, key=lambda k: kern[k]["ms"])
             roofline = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": kern[dom]["frac"],
                         "traffic": traffic_all.get(dom, {}).get("hbm_bytes_per_launch"),
+                        "traffic_source": "%s (rocprofv3 --pmc passes of an earlier run; not measured in this run)" % traffic_file,
+                        "step": {"algorithmic_tflops": FLOP_STEP / (ms_per_step * 1e-3) / 1e12 * world,
+                                 "frac": FLOP_STEP / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
                         "kernels": kern, "kernels_x3_path": kern_x3}
-        step_tflops = FLOP_STEP / (ms_per_step * 1e-3) / 1e12
-        roofline["step_algorithmic_tflops"] = step_tflops * world
-        roofline["step_frac_of_fp32_mfma_peak"] = step_tflops / PEAK_F32_MFMA_TFLOPS
         dtype = ("f32 (storage, accumulation, results); products as exact bf16 triples on the bf16 MFMA (x3)"
                  if args.compute == "x3" else "f32")
         out = {
@@ -249,17 +253,29 @@ def main():
             "unit": "steps/s (1 step = CD-1 update over 4096 rows, 784x1024 fp32)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "value_first_block": rate(blocks[0]), "value_steady": rate(statistics.median(steady)),
+            "rccl_ranks": rccl_ranks,
             "config": {"workload": "rbm_784x1024_cd1_batch4096_fp32 (BASELINE.json configs[1]%s)" % ("" if world == 1 else "; configs[2] shape: 4096 rows per GPU"),
-                       "n_vis": N_VIS, "n_hid": N_HID, "setup_steps": SETUP_STEPS, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
+                       "n_vis": N_VIS, "n_hid": N_HID, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "cd_k": 1, "update_mode": "fused", "lr": "1e-3/4096", "parallelism": "dp%d" % world,
-                       "compute": args.compute, "flop_per_step": FLOP_STEP},
+                       "compute": args.compute, "flop_per_step": FLOP_STEP,
+                       "data_parallel_step": None if comm is None else "kurbm_cd_step_x3_dp (RCCL all-reduce inside libkurbm.so, 2 row ranges)",
+                       "timing": {"blocks": repeats, "steps_per_block": args.steps,
+                                  "value": "N x K / median block time; W = %d untimed warm-up steps before the first block" % args.warmup,
+                                  "value_first_block": "first block alone (cold clocks)",
+                                  "value_steady": "median of %d more blocks after %d further untimed steps" % (repeats, SETTLE_STEPS),
+                                  "block_ms": [b * 1e3 for b in blocks], "steady_block_ms": [b * 1e3 for b in steady]}},
             "paths": paths,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            from oracle import cpu_baseline
+            out["cpu_baseline"] = cpu_baseline.run(N_VIS, N_HID, BATCH)
     if dist.is_initialized():
-        dist.barrier()
+        dist.barrier()   # (gloo: the other ranks wait here, on the host, while rank 0 measures)
+    if comm is not None:
+        dp.destroy_comms()
+    if dist.is_initialized():
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))

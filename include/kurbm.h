@@ -37,9 +37,10 @@
 extern "C" {
 #endif
 
-#define KURBM_ABI_VERSION 1
+#define KURBM_ABI_VERSION 2
 
 typedef struct kurbm_ctx kurbm_ctx;
+typedef struct kurbm_comm kurbm_comm; /* one RCCL communicator + the library's comm stream and events, per GPU */
 typedef void* kurbm_stream_t; /* hipStream_t */
 
 enum {
@@ -47,7 +48,8 @@ enum {
     KURBM_ERR_ARG = -1,         /* bad pointer / shape / alignment */
     KURBM_ERR_HIP = -2,         /* a HIP runtime call failed */
     KURBM_ERR_UNSUPPORTED = -3, /* valid request this build does not implement */
-    KURBM_ERR_WORKSPACE = -4    /* workspace too small */
+    KURBM_ERR_WORKSPACE = -4,   /* workspace too small */
+    KURBM_ERR_COMM = -5         /* RCCL missing or an RCCL call failed */
 };
 
 /* Activation applied to the pre-activation x = in.W(+T) + bias. */
@@ -99,6 +101,10 @@ typedef struct {
     uint64_t row0;      /* global row offset of this shard (data parallel); % 4 == 0 */
     uint32_t step;      /* parameter-update counter                                  */
     uint32_t chain;     /* chain id: stream ids are chain*64 + {2t, 2t-1}            */
+    const void* v_planes;      /* nullable; x3 only: the bf16 planes kurbm_x3_convert_rows made of exactly the rows of
+                                  v_batch -- the step then skips its own conversion (the data matrix is static for
+                                  a whole fit(): rbm.py:211 slices the same V every epoch)               */
+    uint64_t v_planes_stride;  /* kurbm_cd_epoch_x3: bytes between the planes of consecutive batches   */
 } kurbm_cd_opts;
 
 /* ---- context ------------------------------------------------------------------- */
@@ -106,6 +112,10 @@ int kurbm_abi_version(void);
 const char* kurbm_last_error(void);
 int kurbm_ctx_create(int device, kurbm_ctx** out);
 void kurbm_ctx_destroy(kurbm_ctx* ctx);
+/* Tuning / test hook: the library reads its experiment knobs (the KURBM_* variables listed in DESIGN.md) from the
+ * environment once, in kurbm_ctx_create; this sets one of them (by its environment name, e.g. "KURBM_X3_TALL") on a
+ * live context.  -1 = automatic where a knob has an automatic setting.  No production caller needs it. */
+int kurbm_ctx_set_option(kurbm_ctx* ctx, const char* name, int value);
 
 /* ---- RNG test hook: out[r, c] = u(row0 + r, c) under the contract above -------- */
 int kurbm_philox_uniform(kurbm_ctx* ctx, float* out, int rows, int cols, int ld,
@@ -253,9 +263,6 @@ int kurbm_cd_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t
  * step left in `workspace` (same arguments as that step).  stage: 0 v_pos -> bf16 pieces, 1 h_pos half
  * step, 2 v_neg half step(s), 3 h_neg half step, 4 statistics GEMM, 5 slab reduction + parameter
  * update + mirror refresh, 6 mirror refresh alone.  bench.py times the kernels of a step with it.
- * Stages 0 and 9 (= everything but stage 0) also split a step in two for the data-parallel loop: the conversion of the
- * NEXT batch (stage 0; it does not depend on the parameters) runs while the all-reduce of this step's sums is in flight,
- * and the next step starts at stage 9 on the same `rows`.
  */
 int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                            const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts,
@@ -269,8 +276,7 @@ int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
                          kurbm_stream_t stream);
 
 /* kurbm_cd_epoch on the x3 path: every batch of an epoch in one call (fused updates; returns the number of steps).
- * All work is ordered on `stream`.  (KURBM_X3_PIPE=1, an experiment that is off by default: batch t+1 is converted on a
- * side stream owned by the context, joined to `stream` by events, into the second set of v_pos planes of the workspace.) */
+ * All work is ordered on `stream`.  With opts->v_planes the planes of batch t are read at v_planes + t * v_planes_stride. */
 int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* V,
                       int v_pieces, int n_rows, int ldv, int batch_size, const kurbm_cd_opts* opts,
                       void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
@@ -295,11 +301,57 @@ int kurbm_x3_stats_rows(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, siz
 int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                          const float* delta, float lr, int which, kurbm_stream_t stream);
 
+/*
+ * Resident data planes.  RBM.fit slices the same matrix V every epoch (rbm.py:113, :211), so its bf16 images -- the pieces
+ * of the rows row-major and transposed, and their column sums per 64-row band -- are made ONCE per window of rows and a
+ * step given opts->v_planes reads them instead of converting the window again.  `planes` is caller-owned device memory of
+ * kurbm_x3_planes_bytes(rows) bytes per window; its layout follows `rows` (a remainder batch has its own).
+ */
+size_t kurbm_x3_planes_bytes(kurbm_ctx* ctx, int rows, int n_vis, int v_pieces);
+int kurbm_x3_convert_rows(kurbm_ctx* ctx, const float* v, int rows, int ldv, int n_vis, int v_pieces, void* planes,
+                          size_t planes_bytes, kurbm_stream_t stream);
+
 /* One half step on the x3 path (transform / test hook): dir 0 = v->h, 1 = h->v. */
 int kurbm_half_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, int dir,
                        const float* in, int in_pieces, int rows, int ld_in, int act, int noise,
                        const kurbm_rng* rng, float* out_sample, float* out_prob, float* out_u, int ld_out,
                        void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
+/* ---- data parallel: the exchange step ------------------------------------
+ *
+ * The reference has no multi-device path.  Each GPU runs the chain on its rows of the batch (rbm.py:119-124: rows
+ * never interact) and the updates are SUMS over the batch (rbm.py:125-134), so ONE sum all-reduce of the packed
+ * [dW | db_h | db_v] buffer reproduces the single-GPU update up to the order of the fp32 additions.  The collective
+ * is RCCL's ncclAllReduce over xGMI, called from inside this library (bound at run time: librccl.so.1, or the file
+ * KURBM_RCCL_LIB names); the host language only carries the 128-byte unique id from rank 0 to the other ranks.
+ * One process per GPU: kurbm_comm_unique_id on rank 0, kurbm_comm_init_rank everywhere (collective: returns when all
+ * ranks have joined).  One process driving several GPUs: kurbm_comm_init_all (ncclCommInitAll), `out` an array of ndev.
+ */
+#define KURBM_UNIQUE_ID_BYTES 128
+int kurbm_comm_unique_id(void* id, size_t id_bytes);                                    /* ncclGetUniqueId  */
+int kurbm_comm_init_rank(int device, int nranks, int rank, const void* id, size_t id_bytes,
+                         kurbm_comm** out);                                             /* ncclCommInitRank */
+int kurbm_comm_init_all(int ndev, const int* devs, kurbm_comm** out);                   /* ncclCommInitAll  */
+int kurbm_comm_count(const kurbm_comm* comm);   /* ranks as RCCL reports them (ncclCommCount); < 0 = error */
+int kurbm_comm_rank(const kurbm_comm* comm);    /* ncclCommUserRank; < 0 = error */
+void kurbm_comm_destroy(kurbm_comm* comm);
+/* In-place sum over all ranks of buf[0 .. n) (device fp32), ordered on `stream`. */
+int kurbm_allreduce_sum_f32(kurbm_comm* comm, float* buf, size_t n, kurbm_stream_t stream);
+
+/*
+ * The data-parallel x3 step in ONE call: this rank's chain on its `rows` rows (opts->row0 = their global index), the
+ * statistics GEMM in n_chunks row ranges of dW, each range's packed sums all-reduced on the library's comm stream
+ * while the next range is still being computed on `stream` (db_h, db_v travel with the last range), then -- with
+ * opts->apply = 1 -- W, b_h, b_v += lr * (summed delta) and the weight-piece mirror rewritten, in one launch, once the
+ * last all-reduce has landed.  opts->delta_out (packed, required) holds the SUMMED statistics afterwards.  rows = 0
+ * is legal (a rank that owns no rows of a remainder batch contributes zeros; v_batch is not read).  n_chunks <= 0:
+ * the library picks (one range, all-reduced on `stream` itself: on MI355X / ROCm 7 the hand-off between two streams
+ * costs more than a 3.2 MB all-reduce can hide -- DESIGN.md section 5).  Every rank must pass the same n_chunks.  All
+ * work is ordered on `stream` from the caller's point of view.
+ */
+int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                        const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks,
+                        void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
 
 /* *flag (device int) := 1 if some element of x [rows][ld] is not exactly representable in bf16, else 0. */
 int kurbm_bf16_exact(kurbm_ctx* ctx, const float* x, int rows, int cols, int ld, int* flag,

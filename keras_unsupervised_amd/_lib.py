@@ -33,7 +33,8 @@ class Rng(C.Structure):
 class CdOpts(C.Structure):
     _fields_ = [("k", C.c_int32), ("mode", C.c_int32), ("lr", C.c_float), ("apply", C.c_int32),
                 ("delta_out", C.c_void_p), ("v_chain", C.c_void_p),
-                ("seed", C.c_uint64), ("row0", C.c_uint64), ("step", C.c_uint32), ("chain", C.c_uint32)]
+                ("seed", C.c_uint64), ("row0", C.c_uint64), ("step", C.c_uint32), ("chain", C.c_uint32),
+                ("v_planes", C.c_void_p), ("v_planes_stride", C.c_uint64)]
 
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
@@ -45,6 +46,7 @@ SIGNATURES = {
     "kurbm_last_error": (C.c_char_p, []),
     "kurbm_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "kurbm_ctx_destroy": (None, [_vp]),
+    "kurbm_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
     "kurbm_philox_uniform": (_i, [_vp, _vp, _i, _i, _i, _RP, _vp]),
     "kurbm_half_step_vh": (_i, [_vp, _PP, _vp, _i, _i, _i, _i, _RP, _vp, _vp, _i, _vp]),
     "kurbm_half_step_hv": (_i, [_vp, _PP, _vp, _i, _i, _i, _i, _RP, _vp, _vp, _i, _vp]),
@@ -73,8 +75,21 @@ SIGNATURES = {
     "kurbm_x3_stats_rows": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _i, _vp, _sz, _vp]),
     "kurbm_x3_apply_delta": (_i, [_vp, _PP, _vp, _sz, _vp, C.c_float, _i, _vp]),
     "kurbm_half_step_x3": (_i, [_vp, _PP, _vp, _sz, _i, _vp, _i, _i, _i, _i, _i, _RP, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "kurbm_x3_planes_bytes": (_sz, [_vp, _i, _i, _i]),
+    "kurbm_x3_convert_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "kurbm_bf16_exact": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "kurbm_comm_unique_id": (_i, [_vp, _sz]),
+    "kurbm_comm_init_rank": (_i, [_i, _i, _i, _vp, _sz, C.POINTER(_vp)]),
+    "kurbm_comm_init_all": (_i, [_i, C.POINTER(_i), C.POINTER(_vp)]),
+    "kurbm_comm_count": (_i, [_vp]),
+    "kurbm_comm_rank": (_i, [_vp]),
+    "kurbm_comm_destroy": (None, [_vp]),
+    "kurbm_allreduce_sum_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "kurbm_cd_step_x3_dp": (_i, [_vp, _vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _vp, _sz, _vp]),
 }
+
+ABI_VERSION = 2
+UNIQUE_ID_BYTES = 128
 
 _lib = None
 
@@ -92,6 +107,9 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    if lib.kurbm_abi_version() != ABI_VERSION:
+        raise KurbmError("%s implements ABI %d, this package binds ABI %d: rebuild it (make -C keras_unsupervised_amd/csrc)"
+                         % (LIB_PATH, lib.kurbm_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -114,6 +132,10 @@ class Context:
         self.handle = h
         self.device_index = int(device_index)
         self.lib = lib
+
+    def set_option(self, name, value):
+        """Set one experiment knob (its KURBM_* environment name) on this context; -1 = automatic."""
+        check(self.lib.kurbm_ctx_set_option(self.handle, name.encode(), int(value)))
 
     @classmethod
     def get(cls, device_index):

@@ -12,8 +12,29 @@
 
 #include "../../include/kurbm.h"
 #include "kurbm_kernels.h"
+#include "kurbm_comm.h"
 
 using namespace kurbm;
+
+// Experiment knobs.  Every one is read from the environment ONCE, at kurbm_ctx_create, into the context (no getenv on
+// the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
+// planner decide".
+enum { KN_LDPAD, KN_X3_BN, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_SEGMENTS, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
+       KN_UNFUSED_MIRROR, KN_BF16_CFG, KN_X3_STATS_BM, KN_COUNT };
+constexpr int KN_AUTO = -1;
+static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
+    {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
+    {"KURBM_X3_BN", 128},          // 64: 128 x 64 x3 tiles, two workgroups per CU
+    {"KURBM_BF16_SPLIT", KN_AUTO}, // split-K slices of the bf16 / x3 statistics GEMM
+    {"KURBM_X3_FULL", 0},          // 1: all nine piece pairs of a real x real product
+    {"KURBM_X3_SEGMENTS", 0},      // 1: x3 pieces as consecutive k ranges on the rounded-bf16 kernel
+    {"KURBM_X3_TALL", KN_AUTO},    // 0 / 1: never / always 256 x 64 half-step tiles
+    {"KURBM_X3_MFAST", 1},         // block order of the x3 half steps
+    {"KURBM_X3_STATS_MFAST", 0},   // block order of the x3 statistics GEMM
+    {"KURBM_UNFUSED_MIRROR", 0},   // 1: slab reduce and weight-piece mirror as two launches
+    {"KURBM_BF16_CFG", KN_AUTO},   // tile configuration of the rounded-bf16 kernel
+    {"KURBM_X3_STATS_BM", KN_AUTO},// row-tile height of the x3 statistics GEMM (128 / 112)
+};
 
 struct kurbm_ctx {
     int device;
@@ -22,9 +43,7 @@ struct kurbm_ctx {
     int force_cfg[3];   // per layout: KURBM_CFG_VH / KURBM_CFG_HV / KURBM_CFG_OUTER
     int force_split;    // KURBM_SPLIT
     int tile_major;     // KURBM_TILE_MAJOR (default 1): k-slices of a statistics tile share an XCD
-    // kurbm_cd_epoch_x3: batch t+1 is converted on a side stream while step t runs (created on first use)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr};
+    int knob[KN_COUNT];
 };
 
 static int env_int(const char* name, int dflt) {
@@ -43,6 +62,18 @@ static int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+
+namespace kurbm {
+int fail_msg(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace kurbm
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -248,17 +279,25 @@ int kurbm_ctx_create(int device, kurbm_ctx** out) {
     c->force_cfg[LAYOUT_OUTER] = env_int("KURBM_CFG_OUTER", -1);
     c->force_split = env_int("KURBM_SPLIT", -1);
     c->tile_major = env_int("KURBM_TILE_MAJOR", 1);
+    for (int i = 0; i < KN_COUNT; ++i) c->knob[i] = env_int(KNOBS[i].env, KNOBS[i].dflt);
     *out = c;
     return KURBM_OK;
 }
 
+int kurbm_ctx_set_option(kurbm_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return fail(KURBM_ERR_ARG, "null argument");
+    for (int i = 0; i < KN_COUNT; ++i)
+        if (strcmp(name, KNOBS[i].env) == 0) { ctx->knob[i] = value; return KURBM_OK; }
+    if (strcmp(name, "KURBM_CFG_VH") == 0) { ctx->force_cfg[LAYOUT_VH] = value; return KURBM_OK; }
+    if (strcmp(name, "KURBM_CFG_HV") == 0) { ctx->force_cfg[LAYOUT_HV] = value; return KURBM_OK; }
+    if (strcmp(name, "KURBM_CFG_OUTER") == 0) { ctx->force_cfg[LAYOUT_OUTER] = value; return KURBM_OK; }
+    if (strcmp(name, "KURBM_SPLIT") == 0) { ctx->force_split = value; return KURBM_OK; }
+    if (strcmp(name, "KURBM_TILE_MAJOR") == 0) { ctx->tile_major = value; return KURBM_OK; }
+    return fail(KURBM_ERR_ARG, "unknown option %s", name);
+}
+
 void kurbm_ctx_destroy(kurbm_ctx* ctx) {
     if (!ctx) return;
-    for (int i = 0; i < 2; ++i) {
-        if (ctx->ev_main[i]) (void)hipEventDestroy(ctx->ev_main[i]);
-        if (ctx->ev_side[i]) (void)hipEventDestroy(ctx->ev_side[i]);
-    }
-    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
 }
 
@@ -526,17 +565,17 @@ void kurbm_debug_set_off(int mask) { set_debug_off(mask); }
 // ======================================================================================
 // Leading dimension of a bf16 plane = its k extent (+ KURBM_LDPAD elements: an experiment knob.  Row strides
 // that are multiples of 2 KiB were suspected of camping on one L2 channel; padding them changed nothing.)
-static inline int ld_pad(int k) { return k + env_int("KURBM_LDPAD", 0); }
+static inline int ld_pad(const kurbm_ctx* ctx, int k) { return k + ctx->knob[KN_LDPAD]; }
 
 struct Mirror { uint16_t *Wb, *Wtb; int Kh, Kv, ldW, ldWt, pieces; size_t planeW, planeWt, bytes; };
 
-static Mirror carve_mirror(void* base, int n_vis, int n_hid, int pieces) {
+static Mirror carve_mirror(const kurbm_ctx* ctx, void* base, int n_vis, int n_hid, int pieces) {
     Mirror m;
     m.pieces = pieces;
     m.Kh = round_up(n_hid, 128);   // k extent of W  [n_vis][Kh]   (B operand of h->v)
     m.Kv = round_up(n_vis, 128);   // k extent of Wt [n_hid][Kv]   (B operand of v->h)
-    m.ldW = ld_pad(m.Kh);
-    m.ldWt = ld_pad(m.Kv);
+    m.ldW = ld_pad(ctx, m.Kh);
+    m.ldWt = ld_pad(ctx, m.Kv);
     m.planeW = (size_t)n_vis * m.ldW;
     m.planeWt = (size_t)n_hid * m.ldWt;
     char* b = static_cast<char*>(base);
@@ -550,8 +589,6 @@ static Mirror carve_mirror(void* base, int n_vis, int n_hid, int pieces) {
 struct WorkspaceB {
     uint16_t *vb, *vbT, *hb, *hbT, *v2b, *v2bT, *h2b, *hnT, *cb;
     float *part_h, *part_v, *slab, *tmp32;
-    uint16_t *vb_alt = nullptr, *vbT_alt = nullptr;   // x3: a second set of v_pos planes (the epoch call converts batch t+1
-    float* part_v_alt = nullptr;                      //     while step t runs); behind everything else
     int Kv, Kh, Kb, Lv, Lh, Lb, ldh32, ldv32, max_row_tiles;   // K*: k extents; L*: leading dimensions of the bf16 planes
     size_t planeV, planeVT, planeHT;   // distance between the pieces of v_pos (both images) and of h_neg^T
     size_t slab_stride, bytes;
@@ -563,12 +600,12 @@ struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_spli
 // fastest, so a slice is a whole number of k positions
 static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, bool pb, int s_max = 1 << 30) {
     OuterPlanB pl;
-    const bool bn64 = pb && env_int("KURBM_X3_BN", 128) == 64;
+    const bool bn64 = pb && ctx->knob[KN_X3_BN] == 64;
     pl.gm = ceil_div(n_vis, 128);
     pl.gn = ceil_div(n_hid, bn64 ? 64 : 128);
     pl.nkt = round_up(rows, 128) / (pb ? 64 : 128);
     pl.kt_total = nseg * pl.nkt;
-    int s = env_int("KURBM_BF16_SPLIT", ((pb && !bn64 ? 1 : 2) * ctx->ncu) / (pl.gm * pl.gn));
+    int s = ctx->knob[KN_BF16_SPLIT] != KN_AUTO ? ctx->knob[KN_BF16_SPLIT] : ((pb && !bn64 ? 1 : 2) * ctx->ncu) / (pl.gm * pl.gn);
     if (s > s_max) s = s_max;
     if (s < 1) s = 1;
     if (s > pl.nkt) s = pl.nkt;
@@ -581,8 +618,8 @@ static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int
 }
 
 // segment codes of k_gemm_pb: A piece ia against B pieces 0 .. npb-1
-static int pb_codes(int a_pieces, int b_pieces, unsigned set, unsigned long long* codes, int nseg) {
-    const bool full = env_int("KURBM_X3_FULL", 0) != 0;
+static int pb_codes(const kurbm_ctx* ctx, int a_pieces, int b_pieces, unsigned set, unsigned long long* codes, int nseg) {
+    const bool full = ctx->knob[KN_X3_FULL] != 0;
     for (int ia = 0; ia < a_pieces; ++ia) {
         int npb = b_pieces;
         if (a_pieces > 1 && b_pieces > 1 && !full) npb = b_pieces - ia;     // pairs with ia + ib <= 2
@@ -598,7 +635,7 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.Kv = round_up(n_vis, 128);
     w.Kh = round_up(n_hid, 128);
     w.Kb = round_up(rows, 128);
-    w.Lv = ld_pad(w.Kv); w.Lh = ld_pad(w.Kh); w.Lb = ld_pad(w.Kb);
+    w.Lv = ld_pad(ctx, w.Kv); w.Lh = ld_pad(ctx, w.Kh); w.Lb = ld_pad(ctx, w.Kb);
     w.ldh32 = round_up(n_hid, 4);
     w.ldv32 = round_up(n_vis, 4);
     w.max_row_tiles = ceil_div(rows, 128);
@@ -625,12 +662,26 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.part_v = take32((size_t)(ceil_div(rows, 64) + 2 * w.max_row_tiles) * w.ldv32);
     w.slab = take32(w.slab_stride * pl.nsplit_bound);
     w.tmp32 = take32((size_t)rows * (w.ldh32 > w.ldv32 ? w.ldh32 : w.ldv32));       // fp32 plane for the test hook
-    if (pieces == 3) {
-        w.vb_alt = take16(v_pieces * w.planeV); w.vbT_alt = take16(v_pieces * w.planeVT);
-        w.part_v_alt = take32((size_t)(ceil_div(rows, 64) + 2 * w.max_row_tiles) * w.ldv32);
-    }
     w.bytes = off;
     return w;
+}
+
+// The bf16 planes of a window of `rows` data rows, as the x3 step reads them: pieces of v row-major [Kb][Lv] (A operand of
+// the first half step), transposed [n_vis][Lb] (A operand of the positive statistics), and the column sums of each 64-row
+// band (the positive half of db_v).  Same extents as the v_pos planes of a workspace carved for `rows` rows, so a step can
+// read them IN PLACE OF its own conversion (kurbm_cd_opts::v_planes): the data matrix is static for a whole fit().
+struct VPlanes { uint16_t *vb, *vbT; float* part_v; size_t bytes; };
+static VPlanes carve_vplanes(const kurbm_ctx* ctx, const void* base, int rows, int n_vis, int v_pieces) {
+    VPlanes v;
+    const int Kv = round_up(n_vis, 128), Kb = round_up(rows, 128);
+    const size_t planeV = (size_t)Kb * ld_pad(ctx, Kv), planeVT = (size_t)n_vis * ld_pad(ctx, Kb);
+    char* b = static_cast<char*>(const_cast<void*>(base));
+    size_t off = 0;
+    v.vb = reinterpret_cast<uint16_t*>(b + off);  off = align_up(off + v_pieces * planeV * 2);
+    v.vbT = reinterpret_cast<uint16_t*>(b + off); off = align_up(off + v_pieces * planeVT * 2);
+    v.part_v = reinterpret_cast<float*>(b + off); off = align_up(off + (size_t)ceil_div(rows, 64) * round_up(n_vis, 4) * 4);
+    v.bytes = off;
+    return v;
 }
 
 static inline uint32_t inv_of(int nkt) { return nkt > 1 ? (uint32_t)(0x100000000ull / (unsigned)nkt) + 1u : 0u; }
@@ -638,8 +689,8 @@ static inline uint32_t inv_of(int nkt) { return nkt > 1 ? (uint32_t)(0x100000000
 // segment list of a product (a_pieces of A) x (b_pieces of B): all pairs when one side is a single
 // piece; otherwise the pairs with ia + ib <= 2 (the dropped ones are below 2^-24 of the product),
 // or all nine with KURBM_X3_FULL=1
-static int pair_codes(int a_pieces, int b_pieces, unsigned set, unsigned long long* codes, int nseg) {
-    const int maxsum = (a_pieces > 1 && b_pieces > 1 && !env_int("KURBM_X3_FULL", 0)) ? 2 : 4;
+static int pair_codes(const kurbm_ctx* ctx, int a_pieces, int b_pieces, unsigned set, unsigned long long* codes, int nseg) {
+    const int maxsum = (a_pieces > 1 && b_pieces > 1 && !ctx->knob[KN_X3_FULL]) ? 2 : 4;
     for (int ia = 0; ia < a_pieces; ++ia)
         for (int ib = 0; ib < b_pieces; ++ib)
             if (ia + ib <= maxsum) {
@@ -673,13 +724,13 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
     g.A0 = A; g.lda = lda; g.a_plane0 = a_plane;
     g.B0 = vh ? m.Wtb : m.Wb; g.ldb = vh ? m.ldWt : m.ldW; g.b_plane0 = vh ? m.planeWt : m.planeW;
     g.M = rows; g.N = vh ? p->n_hid : p->n_vis; g.K = vh ? m.Kv : m.Kh;
-    if (m.pieces == 3 && !env_int("KURBM_X3_SEGMENTS", 0)) {
+    if (m.pieces == 3 && !ctx->knob[KN_X3_SEGMENTS]) {
         // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip), 128 x 128 tiles
-        g.nseg = pb_codes(a_pieces, 3, 0u, &g.seg_codes, 0);
-        g.cfg = env_int("KURBM_X3_BN", 128) == 64 ? 1 : 0;     // 1: 128 x 64 tiles, 256 threads, two workgroups per CU
+        g.nseg = pb_codes(ctx, a_pieces, 3, 0u, &g.seg_codes, 0);
+        g.cfg = ctx->knob[KN_X3_BN] == 64 ? 1 : 0;     // 1: 128 x 64 tiles, 256 threads, two workgroups per CU
         // 2: 256 x 64 tiles (fewer bytes per k-tile).  Whole 256-row tiles only: the bias partial rows are laid out
         // per 64 rows, two per 128-row tile, and an even number of those is what both tilings agree on
-        const int tall = env_int("KURBM_X3_TALL", -1);
+        const int tall = ctx->knob[KN_X3_TALL];
         if (!g.cfg && ceil_div(rows, 128) % 2 == 0 &&
             (tall == 1 || (tall < 0 && (rows / 256) * ceil_div(g.N, 64) * 4 >= 3 * ctx->ncu))) g.cfg = 2;
         // (64-column tiles: a row-major plane is the next GEMM's A operand, k-padded to 128 -- cover the padded row)
@@ -699,17 +750,17 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.colpart = o.colpart; g.ld_colpart = o.ld_colpart; g.colsign = o.colsign;
         // row tiles fastest: an XCD's run of workgroups then shares ONE column tile, whose weight pieces
         // (the operand loaded straight into registers, one tile ahead) stay in that XCD's L2
-        g.m_fastest = env_int("KURBM_X3_MFAST", 1);
+        g.m_fastest = ctx->knob[KN_X3_MFAST];
         if (o.grid_m_out) *o.grid_m_out = ceil_div(rows, 128);   // (in 128-row units whatever the tile)
         HIP_TRY(launch_gemm_pb(EPI_HALFSTEP, g, st));
         return KURBM_OK;
     }
-    g.nseg = pair_codes(a_pieces, m.pieces, 0u, &g.seg_codes, 0);
+    g.nseg = pair_codes(ctx, a_pieces, m.pieces, 0u, &g.seg_codes, 0);
     // tile choice: 128x128 when that already gives every CU two workgroups; the wave-specialised
     // 128x128 kernel (4 MFMA + 4 loader waves, one workgroup per CU) when there is about one tile per
     // CU; 128x64 tiles (more, smaller workgroups) for small grids
     const int tiles128 = ceil_div(rows, 128) * ceil_div(g.N, 128);
-    g.cfg = env_int("KURBM_BF16_CFG", tiles128 >= 2 * ctx->ncu ? 0 : (2 * tiles128 >= ctx->ncu ? 2 : 1));
+    g.cfg = ctx->knob[KN_BF16_CFG] != KN_AUTO ? ctx->knob[KN_BF16_CFG] : (tiles128 >= 2 * ctx->ncu ? 0 : (2 * tiles128 >= ctx->ncu ? 2 : 1));
     g.grid_m = ceil_div(rows, 128); g.grid_n = ceil_div(g.N, 128) * (g.cfg == 1 ? 2 : 1);   // covers the 128-padded row
     g.nkt = g.K / (g.cfg == 1 ? 64 : 128);
     g.inv_nkt = inv_of(g.nkt);
@@ -733,7 +784,7 @@ static int mirror_refresh_any(kurbm_ctx* ctx, int pieces, const kurbm_params* p,
     if (!ctx) return fail(KURBM_ERR_ARG, "ctx is null");
     if (int e = check_params(p)) return e;
     if (!mirror || !aligned16(mirror)) return fail(KURBM_ERR_ARG, "mirror is null or misaligned");
-    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, pieces);
+    const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, pieces);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
     HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, pieces,
                                m.planeW, m.planeWt, nullptr, 0, static_cast<hipStream_t>(stream)));
@@ -755,10 +806,10 @@ static int half_step_any(kurbm_ctx* ctx, int pieces, int in_pieces, const kurbm_
     if (ld_out % 4 != 0 || ld_out < N) return fail(KURBM_ERR_ARG, "ld_out %% 4 != 0 or ld_out < columns");
     if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, pieces);
+    const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, pieces);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small");
     // the input plane is staged in the larger of the two row-major buffers' shapes: use a private carve
-    const int Kp = ld_pad(round_up(K, 128)), Kb = round_up(rows, 128);   // Kp: leading dimension of the staged input
+    const int Kp = ld_pad(ctx, round_up(K, 128)), Kb = round_up(rows, 128);   // Kp: leading dimension of the staged input
     const size_t plane = (size_t)Kb * Kp;
     const size_t need = align_up(in_pieces * plane * 2);
     if (need > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
@@ -776,14 +827,12 @@ static int half_step_any(kurbm_ctx* ctx, int pieces, int in_pieces, const kurbm_
 
 static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                        const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace,
-                       size_t workspace_bytes, kurbm_stream_t stream, int only = -1, int m_lo = 0, int m_hi = -1, int vset = 0) {
+                       size_t workspace_bytes, kurbm_stream_t stream, int only = -1, int m_lo = 0, int m_hi = -1) {
     // `only` 0..6 (measurement hook kurbm_cd_step_x3_stage): launch just that stage of the sequence, on the planes a
     // previous complete step left in the workspace.  8: the chain alone (stages 0-3, kurbm_cd_chain_x3).  7: the
     // statistics of visible rows [m_lo, m_hi) alone (stages 4-5, kurbm_x3_stats_rows) -- the data-parallel step
     // all-reduces the first rows of dW while the rest is still being computed.
-    // 9: everything but the conversion of v_pos (stage 0), which kurbm_cd_epoch_x3 ran ahead on its side stream into the
-    // v_pos planes `vset` (0 / 1).
-#define KURBM_STAGE(n) (only < 0 || only == (n) || (only == 8 && (n) <= 3) || (only == 7 && ((n) == 4 || (n) == 5)) || (only == 9 && (n) != 0))
+#define KURBM_STAGE(n) (only < 0 || only == (n) || (only == 8 && (n) <= 3) || (only == 7 && ((n) == 4 || (n) == 5)))
     if (m_hi < 0) m_hi = p ? p->n_vis : 0;
     if (!ctx || !o) return fail(KURBM_ERR_ARG, "null argument");
     if (int e = check_params(p)) return e;
@@ -793,20 +842,16 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN)
         return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
     if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1 or 3");
-    if (pieces == 3 && o->mode != KURBM_MODE_VISIBLE_BERNOULLI && env_int("KURBM_X3_SEGMENTS", 0))
+    if (pieces == 3 && o->mode != KURBM_MODE_VISIBLE_BERNOULLI && ctx->knob[KN_X3_SEGMENTS])
         return fail(KURBM_ERR_ARG, "KURBM_X3_SEGMENTS covers MODE_VISIBLE_BERNOULLI only");
     if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
     if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
     if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, pieces);
+    const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, pieces);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
     WorkspaceB w = carve_bf16(ctx, workspace, rows, p->n_vis, p->n_hid, pieces, v_pieces);
     if (w.bytes > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
-    if (vset) {
-        if (!w.vb_alt) return fail(KURBM_ERR_ARG, "no second set of v_pos planes on this path");
-        w.vb = w.vb_alt; w.vbT = w.vbT_alt; w.part_v = w.part_v_alt;
-    }
 
     const bool gauss = (o->mode == KURBM_MODE_VISIBLE_GAUSSIAN);
     const int act_h = gauss ? ACT_RELU : ACT_SIGMOID;
@@ -820,9 +865,16 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
     // (x3: plus the column sums of v_pos per 64-row band, the positive half of the visible-bias statistics)
-    const bool pb = (pieces == 3) && !env_int("KURBM_X3_SEGMENTS", 0);
+    const bool pb = (pieces == 3) && !ctx->knob[KN_X3_SEGMENTS];
     const int gp_v = pb ? ceil_div(rows, 64) : 0;
-    if (KURBM_STAGE(0))
+    // resident planes (kurbm_x3_convert_rows ran once for these rows): no conversion; the positive column sums stay where
+    // they are and the slab reducer adds them in front of the negative ones (same order of additions either way)
+    const float* part_v_pos = nullptr;
+    if (o->v_planes && pb) {
+        if (!aligned16(o->v_planes)) return fail(KURBM_ERR_ARG, "v_planes is misaligned");
+        const VPlanes vp = carve_vplanes(ctx, o->v_planes, rows, p->n_vis, v_pieces);
+        w.vb = vp.vb; w.vbT = vp.vbT; part_v_pos = vp.part_v;
+    } else if (KURBM_STAGE(0))
         HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Lv, w.Kb, w.vbT, w.Lb, p->n_vis, v_pieces, w.planeV,
                                    w.planeVT, pb ? w.part_v : nullptr, w.ldv32, st));
     // h_pos ~ p(h | v_pos)                                          rbm.py:120
@@ -902,17 +954,17 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.grid_m = pl.gm; g.grid_n = pl.gn;
         g.slab = w.slab; g.slab_stride = slab_stride; g.ld_slab = pl.ld_slab;
         if (pb) {   // (piece of v_pos) x h_pos, then v_neg x (all pieces of h_neg), walked segment-fastest
-            g.nseg = pb_codes(v_pieces, 1, 0u, &g.seg_codes, 0);
-            g.nseg = pb_codes(vn_pieces, 3, 1u, &g.seg_codes, g.nseg);
+            g.nseg = pb_codes(ctx, v_pieces, 1, 0u, &g.seg_codes, 0);
+            g.nseg = pb_codes(ctx, vn_pieces, 3, 1u, &g.seg_codes, g.nseg);
             g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
-            g.m_fastest = env_int("KURBM_X3_STATS_MFAST", 0);
-            g.cfg = env_int("KURBM_X3_BN", 128) == 64 ? 1 : 0;
+            g.m_fastest = ctx->knob[KN_X3_STATS_MFAST];
+            g.cfg = ctx->knob[KN_X3_BN] == 64 ? 1 : 0;
             g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
             g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
             HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
         } else {
-            g.nseg = pair_codes(v_pieces, 1, 0u, &g.seg_codes, 0);
-            g.nseg = pair_codes(1, pieces, 1u, &g.seg_codes, g.nseg);
+            g.nseg = pair_codes(ctx, v_pieces, 1, 0u, &g.seg_codes, 0);
+            g.nseg = pair_codes(ctx, 1, pieces, 1u, &g.seg_codes, g.nseg);
             g.nkt = w.Kb / 128; g.inv_nkt = inv_of(g.nkt);
             g.kt_total = g.nseg * g.nkt;
             g.nsplit = pl.nsplit; g.kt_per_split = ceil_div(g.kt_total, g.nsplit);
@@ -935,11 +987,15 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     a.b_h = (ap && (which & 2)) ? p->b_h : nullptr;
     a.delta_bh = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid : nullptr;
     a.part_v = w.part_v; a.nrow_tiles_v = pb ? gp_v + 2 * gm_v : gm_v; a.ld_part_v = w.ldv32;
+    if (part_v_pos) {   // rows [0, gp_v) from the resident planes, then the workspace's negative rows
+        a.part_v = part_v_pos; a.nrow_tiles_v = gp_v;
+        a.part_v2 = w.part_v + (size_t)gp_v * w.ldv32; a.nrow_tiles_v2 = 2 * gm_v;
+    }
     a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
     a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
-    if (sub && m_hi != p->n_vis) { a.part_h = nullptr; a.part_v = nullptr; }   // the bias sums leave with the LAST rows
+    if (sub && m_hi != p->n_vis) { a.part_h = nullptr; a.part_v = nullptr; a.part_v2 = nullptr; }   // the bias sums leave with the LAST rows
     if (sub) a.n_vis_bias = p->n_vis;
-    if (a.W && need_w && !env_int("KURBM_UNFUSED_MIRROR", 0)) {
+    if (a.W && need_w && !ctx->knob[KN_UNFUSED_MIRROR]) {
         // the fp32 master moves: the slab reduction writes the new weights AND their bf16 pieces in one launch
         a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
         a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = pieces;
@@ -961,11 +1017,11 @@ extern "C" {
 
 size_t kurbm_bf16_mirror_bytes(kurbm_ctx* ctx, int n_vis, int n_hid) {
     if (!ctx || n_vis <= 0 || n_hid <= 0) return 0;
-    return carve_mirror(nullptr, n_vis, n_hid, 1).bytes;
+    return carve_mirror(ctx, nullptr, n_vis, n_hid, 1).bytes;
 }
 size_t kurbm_x3_mirror_bytes(kurbm_ctx* ctx, int n_vis, int n_hid) {
     if (!ctx || n_vis <= 0 || n_hid <= 0) return 0;
-    return carve_mirror(nullptr, n_vis, n_hid, 3).bytes;
+    return carve_mirror(ctx, nullptr, n_vis, n_hid, 3).bytes;
 }
 
 int kurbm_bf16_mirror_refresh(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, kurbm_stream_t stream) {
@@ -1015,7 +1071,7 @@ int kurbm_cd_step_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t
 int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
                            int v_pieces, int rows, int ldv, const kurbm_cd_opts* o, int which, int stage, void* workspace,
                            size_t workspace_bytes, kurbm_stream_t stream) {
-    if ((stage < 0 || stage > 6) && stage != 9) return fail(KURBM_ERR_ARG, "stage must be in [0, 6], or 9");
+    if (stage < 0 || stage > 6) return fail(KURBM_ERR_ARG, "stage must be in [0, 6]");
     return cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, which, workspace, workspace_bytes, stream,
                        stage);
 }
@@ -1029,10 +1085,10 @@ int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
     if (bad_matrix(v, ldv, p->n_vis)) return fail(KURBM_ERR_ARG, "v: null, misaligned, ld %% 4 != 0 or ld < n_vis");
     if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, 3);
+    const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, 3);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small");
     // workspace: the bf16 pieces of v [Kb][Lp], then the row partials [column tiles][rows]
-    const int Lp = ld_pad(m.Kv), Kb = round_up(rows, 128);
+    const int Lp = ld_pad(ctx, m.Kv), Kb = round_up(rows, 128);
     const size_t plane = (size_t)Kb * Lp;
     const size_t a_bytes = align_up(v_pieces * plane * 2);
     GemmArgsB g;
@@ -1046,7 +1102,7 @@ int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
     g.A0 = Ab; g.lda = Lp; g.a_plane0 = plane;
     g.B0 = m.Wtb; g.ldb = m.ldWt; g.b_plane0 = m.planeWt;
     g.M = rows; g.N = p->n_hid; g.K = m.Kv;
-    g.nseg = pb_codes(v_pieces, 3, 0u, &g.seg_codes, 0);
+    g.nseg = pb_codes(ctx, v_pieces, 3, 0u, &g.seg_codes, 0);
     g.nkt = g.K / 64; g.inv_nkt = inv_of(g.nkt);
     g.kt_total = g.nseg * g.nkt; g.kt_per_split = g.kt_total; g.nsplit = 1;
     g.m_fastest = 1;
@@ -1066,43 +1122,17 @@ int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_
     if (!ctx || !opts) return fail(KURBM_ERR_ARG, "null argument");
     if (n_rows < 0 || batch_size <= 0) return fail(KURBM_ERR_ARG, "bad row count / batch size");
     if (opts->delta_out || !opts->apply) return fail(KURBM_ERR_ARG, "kurbm_cd_epoch_x3 applies in place: apply = 1, delta_out = null");
+    if (opts->v_planes && opts->v_planes_stride < carve_vplanes(ctx, nullptr, batch_size < n_rows ? batch_size : (n_rows > 0 ? n_rows : 1),
+                                                                 p ? p->n_vis : 1, v_pieces == 3 ? 3 : 1).bytes)
+        return fail(KURBM_ERR_ARG, "v_planes_stride is smaller than the planes of one batch");
     kurbm_cd_opts o = *opts;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // Pipelined: while step t runs on `stream`, batch t+1 is converted (fp32 -> bf16 pieces, both orientations, column
-    // sums) on a side stream into the other set of v_pos planes; it fits beside the launches that leave CUs idle.
-    // Full batches only (a remainder batch lays the workspace out differently), never for one-step epochs.
-    // OFF by default: measured SLOWER (fit at config 2: 155 -> 167-172 us per step, also with the side stream at the lowest
-    // priority) -- the conversion's workgroups take CU slots a GEMM workgroup (144 KB of LDS, all the registers) then waits for.
-    bool pipe = env_int("KURBM_X3_PIPE", 0) != 0 && n_rows >= 2 * batch_size;
-    if (pipe && !ctx->side) {
-        int least = 0, greatest = 0;   // lowest priority: the conversion fills idle CUs, never ahead of a GEMM's workgroups
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_main[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming));
-        }
-    }
     int steps = 0;
-    bool have_pre = false;   // this step's v_pos planes are already on their way (side stream)
     for (int lo = 0; lo < n_rows; lo += batch_size, ++steps) {
         const int rows = (n_rows - lo < batch_size) ? n_rows - lo : batch_size;
-        const int par = steps & 1;
-        const bool next_full = pipe && rows == batch_size && n_rows - (lo + batch_size) >= batch_size;
-        if (next_full) {
-            // the other set was last read by step t-1 (statistics GEMM, slab reduce): all of it is ahead of this event
-            HIP_TRY(hipEventRecord(ctx->ev_main[par], st));
-            HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_main[par], 0));
-            if (int e = cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, V + (size_t)(lo + batch_size) * ldv, rows, ldv, &o, 7,
-                                    workspace, workspace_bytes, ctx->side, 0, 0, -1, par ^ 1))
-                return e;
-            HIP_TRY(hipEventRecord(ctx->ev_side[par ^ 1], ctx->side));
-        }
-        if (have_pre) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side[par], 0));
+        if (opts->v_planes) o.v_planes = static_cast<const char*>(opts->v_planes) + (size_t)steps * opts->v_planes_stride;
         if (int e = cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, V + (size_t)lo * ldv, rows, ldv, &o, 7, workspace,
-                                workspace_bytes, stream, have_pre ? 9 : -1, 0, -1, pipe ? par : 0))
+                                workspace_bytes, stream))
             return e;
-        have_pre = next_full;
         ++o.step;
     }
     return steps;
@@ -1125,12 +1155,70 @@ int kurbm_x3_stats_rows(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, siz
                        m_lo, m_hi);
 }
 
+int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                        const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks,
+                        void* workspace, size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx || !comm || !opts) return fail(KURBM_ERR_ARG, "null argument");
+    if (int e = check_params(p)) return e;
+    if (!opts->delta_out || !aligned16(opts->delta_out)) return fail(KURBM_ERR_ARG, "delta_out (the packed sums) is required, 16-byte aligned");
+    if (comm->device != ctx->device) return fail(KURBM_ERR_ARG, "communicator is on device %d, context on %d", comm->device, ctx->device);
+    if (rows < 0) return fail(KURBM_ERR_ARG, "rows must be >= 0");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t nw = (size_t)p->n_vis * p->n_hid, ntot = nw + p->n_hid + p->n_vis;
+    // row ranges of dW: boundaries on multiples of 128 (the statistics tile), the same on every rank
+    // automatic = ONE range, the all-reduce on the caller's stream.  Measured on MI355X (tools/dp_times.py, 784 x 1024, B = 4096,
+    // 1-rank communicator): one range 139 us per step (= the local step), two 188 us, three 208 us -- a hand-off between two
+    // HIP streams costs ~16 us per event wait and the split statistics GEMM ~13 us, more than the part of a 3.2 MB all-reduce
+    // that the second range could hide.
+    if (n_chunks <= 0) n_chunks = 1;
+    if (n_chunks > kurbm_comm::MAX_CHUNKS) n_chunks = kurbm_comm::MAX_CHUNKS;
+    int bound[kurbm_comm::MAX_CHUNKS + 1];
+    int nc = 0;
+    bound[0] = 0;
+    for (int c = 1; c < n_chunks; ++c) {
+        const int b = (int)((long long)p->n_vis * c / n_chunks) / 128 * 128;
+        if (b > bound[nc] && b < p->n_vis) bound[++nc] = b;
+    }
+    bound[++nc] = p->n_vis;
+    kurbm_cd_opts o = *opts;
+    o.apply = 0;
+    if (rows == 0) HIP_TRY(hipMemsetAsync(o.delta_out, 0, ntot * sizeof(float), st));
+    else if (nc > 1)
+        if (int e = cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream, 8))
+            return e;
+    for (int c = 0; c < nc; ++c) {
+        if (rows > 0) {
+            const int e = (nc == 1)
+                ? cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream)
+                : cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream, 7,
+                              bound[c], bound[c + 1]);
+            if (e) return e;
+        }
+        const size_t lo = (size_t)bound[c] * p->n_hid, hi = (c + 1 == nc) ? ntot : (size_t)bound[c + 1] * p->n_hid;
+        if (nc == 1) {   // nothing to overlap with: the all-reduce stays on the caller's stream, no hand-off
+            if (int e = comm_allreduce_sum(comm, o.delta_out + lo, hi - lo, st)) return e;
+            break;
+        }
+        // this range's sums are complete on `stream`: hand them to the comm stream
+        HIP_TRY(hipEventRecord(comm->ev_ready[c], st));
+        HIP_TRY(hipStreamWaitEvent(comm->stream, comm->ev_ready[c], 0));
+        if (int e = comm_allreduce_sum(comm, o.delta_out + lo, hi - lo, comm->stream)) return e;
+    }
+    if (nc > 1) {
+        HIP_TRY(hipEventRecord(comm->ev_done, comm->stream));
+        HIP_TRY(hipStreamWaitEvent(st, comm->ev_done, 0));
+    }
+    if (opts->apply)
+        return kurbm_x3_apply_delta(ctx, p, mirror, mirror_bytes, o.delta_out, o.lr, 7, stream);
+    return KURBM_OK;
+}
+
 int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* delta,
                          float lr, int which, kurbm_stream_t stream) {
     if (!ctx || !delta) return fail(KURBM_ERR_ARG, "null argument");
     if (int e = check_params(p)) return e;
     if (!mirror || !aligned16(mirror) || !aligned16(delta)) return fail(KURBM_ERR_ARG, "mirror / delta null or misaligned");
-    const Mirror m = carve_mirror(mirror, p->n_vis, p->n_hid, 3);
+    const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, 3);
     if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if ((p->n_hid & 3) || !(which & 1)) {   // packed rows not 16-byte aligned, or W untouched: two launches
@@ -1152,6 +1240,25 @@ int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
     a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
     a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = 3;
     HIP_TRY(launch_reduce_apply_split(a, st));
+    return KURBM_OK;
+}
+
+size_t kurbm_x3_planes_bytes(kurbm_ctx* ctx, int rows, int n_vis, int v_pieces) {
+    if (!ctx || rows <= 0 || n_vis <= 0 || (v_pieces != 1 && v_pieces != 3)) return 0;
+    return carve_vplanes(ctx, nullptr, rows, n_vis, v_pieces).bytes;
+}
+
+int kurbm_x3_convert_rows(kurbm_ctx* ctx, const float* v, int rows, int ldv, int n_vis, int v_pieces, void* planes,
+                          size_t planes_bytes, kurbm_stream_t stream) {
+    if (!ctx) return fail(KURBM_ERR_ARG, "ctx is null");
+    if (rows <= 0 || n_vis <= 0 || (v_pieces != 1 && v_pieces != 3)) return fail(KURBM_ERR_ARG, "bad shape / v_pieces");
+    if (bad_matrix(v, ldv, n_vis)) return fail(KURBM_ERR_ARG, "v: null, misaligned, ld %% 4 != 0 or ld < n_vis");
+    if (!planes || !aligned16(planes)) return fail(KURBM_ERR_ARG, "planes is null or misaligned");
+    const VPlanes vp = carve_vplanes(ctx, planes, rows, n_vis, v_pieces);
+    if (vp.bytes > planes_bytes) return fail(KURBM_ERR_WORKSPACE, "planes too small: need %zu bytes, got %zu", vp.bytes, planes_bytes);
+    const int Kb = round_up(rows, 128), Lv = ld_pad(ctx, round_up(n_vis, 128)), Lb = ld_pad(ctx, Kb);
+    HIP_TRY(launch_f32_to_bf16(v, rows, n_vis, ldv, vp.vb, Lv, Kb, vp.vbT, Lb, n_vis, v_pieces, (size_t)Kb * Lv, (size_t)n_vis * Lb,
+                               vp.part_v, round_up(n_vis, 4), static_cast<hipStream_t>(stream)));
     return KURBM_OK;
 }
 

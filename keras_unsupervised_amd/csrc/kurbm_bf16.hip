@@ -184,14 +184,17 @@ __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int ti
     // bias partials [row tiles][columns] -> column sums: eight loads in flight per lane, fixed order
     const int q = ((int)blockIdx.x - tiles) * 256 + t;
     // in double: the rows are +sum(h_pos) ... -sum(h_neg) per 64 batch rows, two large totals that cancel
-    auto colsum = [](const float* __restrict__ part, int ntiles, int ld, int col) {
+    // (part2: n2 more rows that follow the n1 rows of part as if they were contiguous -- same additions, same order)
+    auto colsum = [](const float* __restrict__ part, int n1, int ld, int col, const float* __restrict__ part2 = nullptr, int n2 = 0) {
+        const int ntiles = n1 + (part2 ? n2 : 0);
+        auto at = [&](int i) { return (double)(i < n1 ? part[(size_t)i * ld + col] : part2[(size_t)(i - n1) * ld + col]); };
         double u[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
         int i = 0;
         for (; i + 8 <= ntiles; i += 8) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) u[e] += (double)part[(size_t)(i + e) * ld + col];
+            for (int e = 0; e < 8; ++e) u[e] += at(i + e);
         }
-        for (; i < ntiles; ++i) u[0] += (double)part[(size_t)i * ld + col];
+        for (; i < ntiles; ++i) u[0] += at(i);
         return (float)(((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7])));
     };
     if (q < a.n_hid) {
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int ti
     } else if (q < a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis)) {
         const int col = q - a.n_hid;
         if (a.part_v) {
-            const float v = colsum(a.part_v, a.nrow_tiles_v, a.ld_part_v, col);
+            const float v = colsum(a.part_v, a.nrow_tiles_v, a.ld_part_v, col, a.part_v2, a.nrow_tiles_v2);
             if (a.delta_bv) a.delta_bv[col] = v;
             if (a.b_v) a.b_v[col] += a.lr * v;
         }

@@ -82,6 +82,8 @@ struct ReduceArgs {
     float* delta_bh;
     const float* part_v;
     int nrow_tiles_v, ld_part_v;
+    const float* part_v2;    // nullable: nrow_tiles_v2 more rows of visible partials, summed AFTER those of part_v as if
+    int nrow_tiles_v2;       // they followed them in memory (the positive rows may live in resident data planes)
     float* b_v;
     float* delta_bv;
     // k_reduce_apply_split (kurbm_bf16.hip): the updated weights also leave as bf16 pieces, both orientations

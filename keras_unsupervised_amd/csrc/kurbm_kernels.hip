@@ -691,14 +691,17 @@ __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
     const int q = ((int)blockIdx.x - a.nblk_w) * 256 + tid;
     // accumulated in double: on the x3 path the rows are +sum(h_pos) ... -sum(h_neg) per 64 batch rows, two large
     // totals that cancel, and an fp32 running sum would lose ~1e-4 of the difference
-    auto colsum = [](const float* __restrict__ part, int ntiles, int ld, int c) {
+    // (part2: n2 more rows that follow the n1 rows of part as if they were contiguous -- same additions, same order)
+    auto colsum = [](const float* __restrict__ part, int n1, int ld, int c, const float* __restrict__ part2 = nullptr, int n2 = 0) {
+        const int ntiles = n1 + (part2 ? n2 : 0);
+        auto at = [&](int r) { return (double)(r < n1 ? part[(size_t)r * ld + c] : part2[(size_t)(r - n1) * ld + c]); };
         double t[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
         int r = 0;
         for (; r + 8 <= ntiles; r += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] += (double)part[(size_t)(r + u) * ld + c];
+            for (int u = 0; u < 8; ++u) t[u] += at(r + u);
         }
-        for (; r < ntiles; ++r) t[0] += (double)part[(size_t)r * ld + c];
+        for (; r < ntiles; ++r) t[0] += at(r);
         return (float)(((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])));
     };
     if (q < a.n_hid) {
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
     } else if (q < a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis)) {
         const int c = q - a.n_hid;
         if (a.part_v) {
-            const float t = colsum(a.part_v, a.nrow_tiles_v, a.ld_part_v, c);
+            const float t = colsum(a.part_v, a.nrow_tiles_v, a.ld_part_v, c, a.part_v2, a.nrow_tiles_v2);
             if (a.delta_bv) a.delta_bv[c] = t;
             if (a.b_v) a.b_v[c] += a.lr * t;
         }

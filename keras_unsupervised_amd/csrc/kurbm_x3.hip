@@ -177,11 +177,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
     }
     constexpr bool SIGNED = (EPI == EPI_SLAB);
     typedef __amdgpu_buffer_rsrc_t rsrc_t;
-    const rsrc_t dA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.baseA), 0, 0xFFFFFFFF, 0x00020000);
+    // B: one descriptor for both operand sets (they live in one workspace), a set is a scalar offset.  A: one descriptor
+    // PER SET -- set 0 of the statistics GEMM (the v_pos planes) may sit in the caller's resident data planes, any distance
+    // from the workspace that holds set 1 -- picked per tile by a scalar select.
+    const rsrc_t dA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.A0), 0, 0xFFFFFFFF, 0x00020000);
+    const rsrc_t dA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.A1 ? g.A1 : g.A0), 0, 0xFFFFFFFF, 0x00020000);
     const rsrc_t dB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.baseB), 0, 0xFFFFFFFF, 0x00020000);
 
     // a tile: the scalar byte offsets of its A rows and of piece 0 of its B rows
-    struct TileRef { uint32_t oa, ob, bplane; uint32_t flip; int npb; };
+    struct TileRef { uint32_t oa, ob, bplane; uint32_t flip; int npb; bool neg; };
     auto tile_of = [&](int t) __attribute__((always_inline)) {
         TileRef r;
         t = t < t_end ? t : t_end - 1;
@@ -196,7 +200,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
         const uint32_t code = (uint32_t)(g.seg_codes >> (5 * seg)) & 31u;
         const bool neg = (code & 16u) != 0u;
         const uint32_t k0 = 2u * (uint32_t)(kt * BKB);
-        r.oa = __builtin_amdgcn_readfirstlane((neg ? g.offA1 : g.offA0) + 2u * (code & 3u) * (uint32_t)(neg ? g.a_plane1 : g.a_plane0) + k0);
+        r.oa = __builtin_amdgcn_readfirstlane(2u * (code & 3u) * (uint32_t)(neg ? g.a_plane1 : g.a_plane0) + k0);
+        r.neg = __builtin_amdgcn_readfirstlane((int)neg) != 0;
         r.ob = __builtin_amdgcn_readfirstlane((neg ? g.offB1 : g.offB0) + k0);
         r.bplane = __builtin_amdgcn_readfirstlane(2u * (uint32_t)(neg ? g.b_plane1 : g.b_plane0));
         r.flip = neg ? 0x80008000u : 0u;   // sign bits of a bf16 pair: set 1 enters negated
@@ -214,9 +219,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
         return;   // timing-only build: no global loads (the registers keep whatever they hold)
 #endif
         if (part == 0) {
+            if (r.neg) {   // (wave-uniform)
 #pragma unroll
-            for (int it = 0; it < NA; ++it)
-                R.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA, goffA[it], r.oa, 0));
+                for (int it = 0; it < NA; ++it)
+                    R.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA1, goffA[it], r.oa, 0));
+            } else {
+#pragma unroll
+                for (int it = 0; it < NA; ++it)
+                    R.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA0, goffA[it], r.oa, 0));
+            }
         } else {
             const int p = part - 1;
             const uint32_t so = __builtin_amdgcn_readfirstlane(r.ob + (uint32_t)(p < r.npb ? p : r.npb - 1) * r.bplane);
@@ -743,16 +754,14 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
         if (base != last_base) { last_base = base; nth = 0; }
         g.stamps = base ? base + (size_t)(nth++) * 65536 : nullptr;
     }
-    {   // one descriptor per operand
-        const uint16_t* a1 = g.A1 ? g.A1 : g.A0;
+    {   // B: one descriptor for both sets (base = the lower pointer; both lie in one workspace).  A: a descriptor per set
         const uint16_t* b1 = g.B1 ? g.B1 : g.B0;
-        g.baseA = g.A0 < a1 ? g.A0 : a1;
+        g.baseA = g.A0;
         g.baseB = g.B0 < b1 ? g.B0 : b1;
-        const size_t oa0 = (size_t)(g.A0 - g.baseA) * 2, oa1 = (size_t)(a1 - g.baseA) * 2;
         const size_t ob0 = (size_t)(g.B0 - g.baseB) * 2, ob1 = (size_t)(b1 - g.baseB) * 2;
         const size_t lim = 0x7FFFFFFFull;   // scalar offset + plane + k must stay below 4 GiB
-        if (oa0 > lim || oa1 > lim || ob0 > lim || ob1 > lim) return hipErrorInvalidValue;
-        g.offA0 = (uint32_t)oa0; g.offA1 = (uint32_t)oa1; g.offB0 = (uint32_t)ob0; g.offB1 = (uint32_t)ob1;
+        if (ob0 > lim || ob1 > lim || 4 * g.a_plane0 > lim || 4 * g.a_plane1 > lim) return hipErrorInvalidValue;
+        g.offA0 = g.offA1 = 0u; g.offB0 = (uint32_t)ob0; g.offB1 = (uint32_t)ob1;
     }
     g.side = (g.prob_f32 != nullptr) || (g.out_u != nullptr);
     const int nblk = g.grid_m * g.grid_n * g.nsplit;

@@ -7,7 +7,9 @@ weights.  Both lose part of an RBM: `get_config` omits `mode` (reference ku/ebm/
 
     <stem>.json          get_config() (hps, output_dim, name, mode, seed, update_mode, cd_k, persistent)
                          + input_dim + the RNG counters, so a reloaded RBM continues the same stream
-    <stem>.safetensors   rbm_weight [n_vis, n_hid], rbm_hidden_bias [n_hid], rbm_visible_bias [n_vis], fp32
+    <stem>.safetensors   rbm_weight [n_vis, n_hid], rbm_hidden_bias [n_hid], rbm_visible_bias [n_vis], fp32;
+                         with persistent=True also v_chain [batch_size, n_vis], the fantasy particles, so that a
+                         reloaded RBM continues the chain it was saved with
 
 and a DBN checkpoint is a JSON list of layer stems.
 """
@@ -32,9 +34,12 @@ def save_rbm(rbm, stem):
     os.makedirs(os.path.dirname(os.path.abspath(stem)), exist_ok=True)
     with open(stem + ".json", "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
-    save_file({"rbm_weight": np.ascontiguousarray(W, dtype=np.float32),
+    tensors = {"rbm_weight": np.ascontiguousarray(W, dtype=np.float32),
                "rbm_hidden_bias": np.ascontiguousarray(b_h, dtype=np.float32),
-               "rbm_visible_bias": np.ascontiguousarray(b_v, dtype=np.float32)}, stem + ".safetensors")
+               "rbm_visible_bias": np.ascontiguousarray(b_v, dtype=np.float32)}
+    if rbm._v_chain is not None:
+        tensors["v_chain"] = np.ascontiguousarray(rbm._v_chain.to_numpy(), dtype=np.float32)
+    save_file(tensors, stem + ".safetensors")
     return stem + ".json", stem + ".safetensors"
 
 
@@ -56,6 +61,12 @@ def load_rbm(stem, device=None):
     rbm.build((None, meta["input_dim"]))
     rbm._update_count = int(meta.get("update_count", 0))
     rbm._call_count = int(meta.get("call_count", 0))
+    if "v_chain" in t:
+        from .engine import DeviceMatrix, device_guard
+        if t["v_chain"].shape[1] != meta["input_dim"]:
+            raise ValueError("checkpoint tensors do not match its config")
+        with device_guard(rbm._dev.device):
+            rbm._v_chain = DeviceMatrix.from_host(t["v_chain"], rbm._dev.device)
     return rbm
 
 

@@ -64,7 +64,7 @@ class DBN(object):
         V_p, kind = self._to_device(layers[0], V)
         for rbm_layer in layers:
             V_p = rbm_layer.transform(V_p)
-        return V_p if kind == "device" else (V_p.view() if kind == "torch" else V_p.to_numpy())
+        return layers[0]._ret(V_p, kind, False)
 
     def inv_transform(self, H):
         """Reverse chain of layer.inv_transform (dbn.py:77-95, loop repaired)."""
@@ -74,4 +74,4 @@ class DBN(object):
             raise ValueError("inv_transform needs built RBM layers")
         for rbm_layer in reversed(layers):
             H_p = rbm_layer.inv_transform(H_p)
-        return H_p if kind == "device" else (H_p.view() if kind == "torch" else H_p.to_numpy())
+        return layers[0]._ret(H_p, kind, False)

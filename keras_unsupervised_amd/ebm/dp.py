@@ -1,28 +1,22 @@
 """Data-parallel sharding of a CD batch over the GPUs of one node.
 
-The Gibbs chain of a row never looks at another row (reference ku/ebm/rbm.py:119-124), and
-the updates are SUMS over the batch (rbm.py:125-134), so rank r runs the chain on its own
-rows and one sum all-reduce of the packed [dW | db_h | db_v] buffer (RCCL over xGMI; `nccl`
-backend of torch.distributed) reproduces the single-GPU update up to fp32 summation order.
-The Philox counters use the global row index, so the draws do not depend on the GPU count.
+The Gibbs chain of a row never looks at another row (reference ku/ebm/rbm.py:119-124), and the updates are SUMS
+over the batch (rbm.py:125-134), so rank r runs the chain on its own rows and one sum all-reduce of the packed
+[dW | db_h | db_v] buffer reproduces the single-GPU update up to fp32 summation order.  The Philox counters use
+the global row index, so the draws do not depend on the GPU count.
 
-Everything here is host logic on torch tensors; it runs unchanged on CPU tensors with the
-`gloo` backend, which is how tests/test_dp_gloo.py covers the N > 1 path without GPUs.
+The collective is RCCL's ncclAllReduce over xGMI, called INSIDE libkurbm.so (include/kurbm.h: kurbm_comm_*,
+kurbm_allreduce_sum_f32, kurbm_cd_step_x3_dp -- the last one overlaps the all-reduce of the first rows of dW with
+the statistics GEMM of the rest, on a comm stream the library owns).  torch.distributed is used for two things
+only: naming (rank, world size), and carrying the 128-byte RCCL unique id from rank 0 to the others when the
+communicator is created.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
-
-import os
-
-# Off by default.  Measured on one MI355X (tools/dp_step_times.py, config 2): the statistics of rows [0,384) and
-# [384,784) take 25.6 + 33.9 us against 46.2 us in one piece, so hiding the first all-reduce (~30 us of an estimated
-# ~56 us at 8 GPUs) under the second range nets ~3 us, and the extra launches make the step host-bound.
-OVERLAP_ROW_RANGES = os.environ.get("KURBM_DP_OVERLAP", "0") == "1"
-# x3 data-parallel step: convert the next batch while this step's all-reduce is in flight (X3Pipeline).  OFF by default:
-# on one rank (1-rank RCCL group, nothing to hide under) the step got 10 us LONGER with the host well ahead of the GPU
-# (tools/dp_host_time.py: 150.6 -> 161.6 us), and the N > 1 case cannot be measured on the one-GPU boxes of this build.
-PRECONVERT = os.environ.get("KURBM_DP_PRECONVERT", "0") == "1"
+from .. import _lib
 
 
 def world():
@@ -32,53 +26,94 @@ def world():
     return 0, 1
 
 
-def shard_rows(n_rows, world_size, rank):
+def shard_rows(n_rows, world_size, rank, of=None):
     """Rows [lo, hi) of an n_rows batch owned by `rank`.
 
     Shard starts are multiples of 4: one Philox block covers 4 consecutive rows of a column
     (include/kurbm.h), so a shard must not split a block.  Later ranks may own no rows of a
     small remainder batch; they still take part in the all-reduce with a zero delta.
+    `of` (>= n_rows): cut the shards as for a batch of `of` rows and clip them to n_rows.  Persistent chains need
+    that -- row j of the fantasy particles must live on the same rank in the full batches and in the remainder
+    batch, or a rank would continue a stale copy of it.
     """
-    per = -(-n_rows // world_size)
+    per = -(-(n_rows if of is None else max(of, n_rows)) // world_size)
     per = (per + 3) // 4 * 4
     lo = min(rank * per, n_rows)
     hi = min(lo + per, n_rows)
     return lo, hi
 
 
-def allreduce_sum_(delta, async_op=False):
-    """In-place sum of the packed delta over all ranks (no-op without a process group)."""
-    if dist.is_available() and dist.is_initialized():
-        return dist.all_reduce(delta, op=dist.ReduceOp.SUM, async_op=async_op)
-    return None
+class Comm:
+    """This process's RCCL communicator behind the C ABI (kurbm_comm_init_rank), plus the comm stream and events
+    libkurbm.so owns for the chunked data-parallel step."""
+
+    def __init__(self, device, rank, world_size, unique_id):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES)
+        _lib.check(self.lib.kurbm_comm_init_rank(int(self.device.index), int(world_size), int(rank), buf,
+                                                 _lib.UNIQUE_ID_BYTES, C.byref(h)))
+        self.handle = h
+        self.rank, self.world_size = int(rank), int(world_size)
+
+    @staticmethod
+    def new_unique_id():
+        lib = _lib.load()
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        _lib.check(lib.kurbm_comm_unique_id(buf, _lib.UNIQUE_ID_BYTES))
+        return bytes(buf.raw)
+
+    def count(self):
+        """Ranks as RCCL itself reports them (ncclCommCount)."""
+        n = self.lib.kurbm_comm_count(self.handle)
+        if n < 0:
+            _lib.check(n)
+        return n
+
+    def allreduce_sum_(self, t):
+        """In-place sum over all ranks of a contiguous fp32 device tensor, ordered on torch's current stream."""
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.lib.kurbm_allreduce_sum_f32(self.handle, t.data_ptr(), t.numel(), st))
+        return t
+
+    def barrier(self):
+        """All ranks have reached this point and their devices are idle: a one-float all-reduce, then a device sync."""
+        if getattr(self, "_token", None) is None:
+            self._token = torch.zeros(4, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        self.allreduce_sum_(self._token)
+        torch.cuda.synchronize(self.device)
+
+    def destroy(self):
+        if self.handle:
+            self.lib.kurbm_comm_destroy(self.handle)
+            self.handle = None
 
 
-class X3Pipeline:
-    """The data-parallel x3 step with the NEXT batch's conversion (fp32 -> bf16 planes, both orientations, column sums;
-    independent of the parameters) enqueued while this step's all-reduce is in flight:
+_comms = {}
 
-        [convert t]  chain t, statistics t, packed sums   all-reduce t (RCCL stream)   apply t   chain t+1 ...
-                                                          convert t+1 (compute stream)
 
-    `nxt` = (row_start, rows) of the rows this rank takes next, or None.  Only batches of the same row count are
-    pre-converted (the workspace layout follows the row count)."""
+def get_comm(device):
+    """The communicator of `device` in the default process group, created on first use (collective: every rank must
+    reach its first data-parallel step).  Rank 0 draws the RCCL unique id; torch.distributed carries its bytes."""
+    device = torch.device(device)
+    comm = _comms.get(device)
+    if comm is None:
+        rank, n = world()
+        box = [Comm.new_unique_id() if rank == 0 else None]
+        if n > 1:
+            with torch.cuda.device(device):
+                dist.broadcast_object_list(box, src=0)
+        comm = _comms[device] = Comm(device, rank, n, box[0])
+    return comm
 
-    def __init__(self, eng):
-        self.eng = eng
-        self.ready = None
 
-    def step(self, V, rows, lo, lr, seed, step, nxt=None, **kw):
-        eng = self.eng
-        part = "rest" if self.ready == (id(V), lo, rows) else None
-        eng.cd_step(V, rows, lo, lr, seed, step, apply=False, emit_delta=True, compute="x3", part=part, **kw)
-        work = allreduce_sum_(eng.delta_buffer(), async_op=True)
-        self.ready = None
-        if nxt is not None and nxt[1] == rows:
-            eng.cd_step(V, rows, nxt[0], lr, seed, step + 1, apply=False, emit_delta=True, compute="x3", part="convert", **kw)
-            self.ready = (id(V), nxt[0], rows)
-        if work is not None:
-            work.wait()
-        eng.apply_delta(lr, compute="x3")
+def destroy_comms():
+    for comm in _comms.values():
+        comm.destroy()
+    _comms.clear()
 
 
 def packed_size(n_vis, n_hid):
@@ -100,24 +135,3 @@ def pack(dW, db_h, db_v, out=None):
     b.copy_(db_h)
     c.copy_(db_v)
     return out
-
-
-def x3_sums_overlapped(eng, v, rows, row_start, lr, seed, step, k=1, row0=0, v_chain=None, v_chain_row=0):
-    """Data-parallel x3 step up to the summed delta: the chain, then the statistics in two row ranges of dW,
-    the all-reduce of the first range running while the second is still being computed.  Leaves the all-reduced
-    packed sums in eng.delta_buffer().  (Without a process group the all-reduces are no-ops.)"""
-    nv, nh = eng.n_vis, eng.n_hid
-    delta = eng.delta_buffer()
-    eng.cd_chain_x3(v, rows, row_start, lr, seed, step, k=k, row0=row0, v_chain=v_chain, v_chain_row=v_chain_row)
-    m = (nv // 2) // 128 * 128
-    if m < 128:                                   # too few visible rows to split on a tile boundary
-        eng.x3_stats_rows(v, rows, row_start, 0, nv, lr, seed, step, k=k, row0=row0)
-        allreduce_sum_(delta)
-        return
-    eng.x3_stats_rows(v, rows, row_start, 0, m, lr, seed, step, k=k, row0=row0)
-    w1 = allreduce_sum_(delta[: m * nh], async_op=True)
-    eng.x3_stats_rows(v, rows, row_start, m, nv, lr, seed, step, k=k, row0=row0)
-    w2 = allreduce_sum_(delta[m * nh:], async_op=True)
-    for w in (w1, w2):
-        if w is not None:
-            w.wait()

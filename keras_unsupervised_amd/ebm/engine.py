@@ -5,6 +5,7 @@ PyTorch is used for exactly three things here: owning device memory (``torch.zer
 of the contrastive-divergence path happens inside ``libkurbm.so``.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -42,6 +43,12 @@ def resolve_device(device=None):
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     return device
+
+
+def device_guard(device):
+    """`with` context that makes a ROCm device current (a no-op for any other device type)."""
+    import contextlib
+    return torch.cuda.device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
 
 
 class DeviceMatrix:
@@ -85,6 +92,39 @@ class DeviceMatrix:
     def view(self):
         """[rows, cols] torch view (device)."""
         return self.t[: self.rows, : self.cols]
+
+
+class ResidentPlanes:
+    """bf16 planes (kurbm_x3_convert_rows) of windows of rows of a data matrix, made once and read by every x3 step on
+    those rows instead of a per-step conversion: fit() walks the same windows every epoch (rbm.py:113, :211)."""
+
+    def __init__(self, eng, v, windows, v_pieces):
+        self.v, self.v_pieces = v, int(v_pieces)
+        self.windows = [(int(lo), int(rows)) for lo, rows in windows]
+        max_rows = max([rows for _, rows in self.windows] + [1])
+        self.stride = int(eng.lib.kurbm_x3_planes_bytes(eng.ctx.handle, max_rows, eng.n_vis, self.v_pieces))
+        if self.stride == 0:
+            raise _lib.KurbmError("kurbm_x3_planes_bytes failed")
+        self.buf = torch.empty(max(len(self.windows), 1) * self.stride, dtype=torch.uint8, device=eng.device)
+        self.slot = {}
+        for t, (lo, rows) in enumerate(self.windows):
+            if rows <= 0:
+                continue
+            check(eng.lib.kurbm_x3_convert_rows(eng.ctx.handle, v.ptr(lo), rows, v.ld, eng.n_vis, self.v_pieces,
+                                                self.buf.data_ptr() + t * self.stride, self.stride, eng._stream()))
+            self.slot[(lo, rows)] = t
+
+    def ptr(self, v, row_start, rows, v_pieces):
+        """Device address of the planes of rows [row_start, +rows) of v, or None if these are not planes of them."""
+        t = self.slot.get((int(row_start), int(rows)))
+        if t is None or v is not self.v or v_pieces != self.v_pieces:
+            return None
+        return self.buf.data_ptr() + t * self.stride
+
+    def uniform(self, row_start, n_rows, batch_size):
+        """True if the windows are exactly the contiguous batches of rows [row_start, +n_rows) (kurbm_cd_epoch_x3)."""
+        want = [(row_start + lo, min(batch_size, n_rows - lo)) for lo in range(0, n_rows, batch_size)]
+        return want == self.windows
 
 
 class DeviceRBM:
@@ -216,16 +256,39 @@ class DeviceRBM:
                      ld_out, self._stream()))
         return out
 
+    def _x3_pieces(self, v, v_chain, mode):
+        """Pieces per element of the batch (and of the persistent chain) on the x3 path: 1 when every value is exactly a
+        bf16 value, else 3.  The data matrix is looked at once.  The chain is REWRITTEN by every step -- 0/1 states in
+        Bernoulli mode, real-valued N(loc, 1) draws in Gaussian mode (rbm.py:64-66) -- so nothing is cached for it beyond
+        what the library itself is known to have written there."""
+        vp = self.v_pieces(v)
+        if v_chain is not None and vp == 1:
+            vp = 3 if mode == MODE_VISIBLE_GAUSSIAN else self.v_pieces(v_chain)
+        return vp
+
+    def make_planes(self, v, windows, mode=MODE_VISIBLE_BERNOULLI, v_chain=None):
+        """ResidentPlanes of `windows` = [(row_start, rows), ...] of DeviceMatrix v for the x3 steps of a fit(), or None
+        when they would not fit comfortably in the free HBM (the steps then convert their rows themselves)."""
+        with torch.cuda.device(self.device):
+            vp = self._x3_pieces(v, v_chain, mode)
+            max_rows = max([rows for _, rows in windows] + [1])
+            need = len(windows) * int(self.lib.kurbm_x3_planes_bytes(self.ctx.handle, max_rows, self.n_vis, vp))
+            free, _ = torch.cuda.mem_get_info(self.device)
+            if need == 0 or need > free // 2:
+                return None
+            return ResidentPlanes(self, v, windows, vp)
+
+    def _chain_written(self, v_chain, mode):
+        if v_chain is not None:
+            v_chain.bf16_exact = True if mode == MODE_VISIBLE_BERNOULLI else None
+
     def cd_step(self, v, rows, row_start, lr, seed, step, k=1, mode=MODE_VISIBLE_BERNOULLI, chain=0,
                 which=WHICH_ALL, apply=True, emit_delta=False, v_chain=None, row0=0, v_chain_row=0, bf16=False,
-                compute=None, part=None):
+                compute=None, planes=None):
         """One CD-k update on rows [row_start, row_start+rows) of DeviceMatrix v.
 
         compute: 'fp32' (fp32 MFMA), 'x3' (fp32 values as exact bf16 triples on the bf16 MFMA),
-        'bf16' (operands rounded to bf16).
-        part (x3 only): 'convert' = only the conversion of these rows into the workspace's v_pos planes; 'rest' = the
-        step on planes a 'convert' of the same rows left there (dp.X3Pipeline: the conversion of the next batch runs
-        under the all-reduce of this one)."""
+        'bf16' (operands rounded to bf16).  planes: ResidentPlanes holding these rows (x3: no per-step conversion)."""
         compute = compute or ("bf16" if bf16 else "fp32")
         with torch.cuda.device(self.device):
             opts = CdOpts(int(k), int(mode), float(lr), 1 if apply else 0,
@@ -240,20 +303,14 @@ class DeviceRBM:
                 if apply and (which & 1):
                     self._weights_written(kept=1)
             elif compute == "x3":
-                vp = self.v_pieces(v)
-                if v_chain is not None and vp == 1:
-                    vp = self.v_pieces(v_chain)
+                vp = self._x3_pieces(v, v_chain, mode)
                 mir, ws = self.mirror(3), self.workspace_bf16(rows, k, 3, vp)
-                if part is None:
-                    check(self.lib.kurbm_cd_step_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
-                                                    v.ptr(row_start), vp, rows, v.ld, C.byref(opts), int(which),
-                                                    ws.data_ptr(), ws.numel(), self._stream()))
-                else:
-                    stage = {"convert": 0, "rest": 9}[part]
-                    check(self.lib.kurbm_cd_step_x3_stage(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
-                                                          v.ptr(row_start), vp, rows, v.ld, C.byref(opts), int(which), stage,
-                                                          ws.data_ptr(), ws.numel(), self._stream()))
-                if apply and (which & 1) and part != "convert":
+                if planes is not None:
+                    opts.v_planes = planes.ptr(v, row_start, rows, vp)
+                check(self.lib.kurbm_cd_step_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                                v.ptr(row_start), vp, rows, v.ld, C.byref(opts), int(which),
+                                                ws.data_ptr(), ws.numel(), self._stream()))
+                if apply and (which & 1):
                     self._weights_written(kept=3)
             elif compute == "fp32":
                 ws = self.workspace(rows, k)
@@ -263,31 +320,41 @@ class DeviceRBM:
                     self._weights_written()
             else:
                 raise ValueError("compute must be 'fp32', 'x3' or 'bf16', got %r" % (compute,))
+        self._chain_written(v_chain, mode)
 
-    def _x3_opts(self, v, rows, k, lr, seed, step, chain, row0, v_chain, v_chain_row):
-        vp = self.v_pieces(v)
-        if v_chain is not None and vp == 1:
-            vp = self.v_pieces(v_chain)
-        opts = CdOpts(int(k), MODE_VISIBLE_BERNOULLI, float(lr), 0, self.delta_buffer().data_ptr(),
-                      v_chain.ptr(v_chain_row) if v_chain is not None else None,
-                      int(seed), int(row0), int(step) & 0xFFFFFFFF, int(chain))
-        return vp, opts, self.mirror(3), self.workspace_bf16(rows, k, 3, vp)
-
-    def cd_chain_x3(self, v, rows, row_start, lr, seed, step, k=1, chain=0, row0=0, v_chain=None, v_chain_row=0):
-        """The Gibbs chain of an x3 step alone (data-parallel step: statistics follow through x3_stats_rows)."""
-        with torch.cuda.device(self.device):
-            vp, opts, mir, ws = self._x3_opts(v, rows, k, lr, seed, step, chain, row0, v_chain, v_chain_row)
-            check(self.lib.kurbm_cd_chain_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
-                                             v.ptr(row_start), vp, rows, v.ld, C.byref(opts), ws.data_ptr(), ws.numel(),
-                                             self._stream()))
-
-    def x3_stats_rows(self, v, rows, row_start, m_lo, m_hi, lr, seed, step, k=1, chain=0, row0=0):
-        """Packed sums of visible rows [m_lo, m_hi) of the chain cd_chain_x3 left in the workspace -> delta_buffer()."""
-        with torch.cuda.device(self.device):
-            vp, opts, mir, ws = self._x3_opts(v, rows, k, lr, seed, step, chain, row0, None, 0)
-            check(self.lib.kurbm_x3_stats_rows(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
-                                               v.ptr(row_start), vp, rows, v.ld, C.byref(opts), int(m_lo), int(m_hi),
-                                               ws.data_ptr(), ws.numel(), self._stream()))
+    def cd_step_dp(self, comm, v, rows, row_start, lr, seed, step, k=1, mode=MODE_VISIBLE_BERNOULLI, chain=0, row0=0,
+                   v_chain=None, v_chain_row=0, compute="x3", n_chunks=0, planes=None):
+        """One data-parallel CD-k update: this rank's chain on rows [row_start, +rows) of v (`row0` = their index in
+        the global batch), the packed sums all-reduced over `comm` (dp.Comm), the summed update applied.  rows may be 0
+        (a rank without rows of a remainder batch still joins the all-reduce).  On the x3 path all of it is ONE library
+        call (kurbm_cd_step_x3_dp) that overlaps the all-reduce of the first rows of dW with the statistics GEMM of the
+        rest; the other paths run emit -> kurbm_allreduce_sum_f32 -> apply."""
+        delta = self.delta_buffer()
+        n_chunks = n_chunks or int(os.environ.get("KURBM_DP_CHUNKS", "0"))      # 0: the library's choice (one range)
+        if compute == "x3":
+            with torch.cuda.device(self.device):
+                vp = self._x3_pieces(v, v_chain, mode)
+                mir, ws = self.mirror(3), self.workspace_bf16(max(rows, 1), k, 3, vp)
+                opts = CdOpts(int(k), int(mode), float(lr), 1, delta.data_ptr(),
+                              v_chain.ptr(v_chain_row) if v_chain is not None else None,
+                              int(seed), int(row0), int(step) & 0xFFFFFFFF, int(chain))
+                if planes is not None and rows > 0:
+                    opts.v_planes = planes.ptr(v, row_start, rows, vp)
+                check(self.lib.kurbm_cd_step_x3_dp(self.ctx.handle, comm.handle, C.byref(self.params), mir.data_ptr(),
+                                                   mir.numel(), v.ptr(row_start), vp, int(rows), v.ld, C.byref(opts),
+                                                   int(n_chunks), ws.data_ptr(), ws.numel(), self._stream()))
+            self._weights_written(kept=3)
+            self._mirrors[3][1] = False
+            if rows > 0:
+                self._chain_written(v_chain, mode)
+            return
+        if rows > 0:
+            self.cd_step(v, rows, row_start, lr, seed, step, k=k, mode=mode, chain=chain, apply=False, emit_delta=True,
+                         v_chain=v_chain, row0=row0, v_chain_row=v_chain_row, compute=compute)
+        else:
+            delta.zero_()
+        comm.allreduce_sum_(delta)
+        self.apply_delta(lr, compute=compute)
 
     def cd_step_x3_stage(self, v, rows, row_start, lr, seed, step, stage):
         """Measurement hook (bench.py): ONE launch of the x3 CD-1 sequence on the planes the previous
@@ -303,23 +370,24 @@ class DeviceRBM:
                 self._weights_written(kept=3)
 
     def cd_epoch(self, v, n_rows, batch_size, lr, seed, step0, k=1, mode=MODE_VISIBLE_BERNOULLI, v_chain=None,
-                 compute="fp32", row_start=0):
+                 compute="fp32", row_start=0, planes=None):
         """All batches of rows [row_start, row_start + n_rows) in ONE library call (fused updates, no score); returns #steps."""
         if compute == "x3":
             with torch.cuda.device(self.device):
-                vp = self.v_pieces(v)
-                if v_chain is not None and vp == 1:
-                    vp = self.v_pieces(v_chain)
+                vp = self._x3_pieces(v, v_chain, mode)
                 rows = min(batch_size, max(n_rows, 1))
                 mir, ws = self.mirror(3), self.workspace_bf16(rows, k, 3, vp)
                 opts = CdOpts(int(k), int(mode), float(lr), 1, None, v_chain.ptr() if v_chain is not None else None,
                               int(seed), 0, int(step0) & 0xFFFFFFFF, 0)
+                if planes is not None and planes.v is v and planes.v_pieces == vp and planes.uniform(row_start, n_rows, batch_size):
+                    opts.v_planes, opts.v_planes_stride = planes.buf.data_ptr(), planes.stride
                 n = self.lib.kurbm_cd_epoch_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), v.ptr(row_start), vp,
                                                int(n_rows), v.ld, int(batch_size), C.byref(opts), ws.data_ptr(), ws.numel(),
                                                self._stream())
                 if n < 0:
                     check(n)
             self._weights_written(kept=3)
+            self._chain_written(v_chain, mode)
             return n
         with torch.cuda.device(self.device):
             ws = self.workspace(min(batch_size, max(n_rows, 1)), k)
@@ -330,6 +398,7 @@ class DeviceRBM:
             if n < 0:
                 check(n)
         self._weights_written()
+        self._chain_written(v_chain, mode)
         return n
 
     def half_step_bf16(self, direction, x, rows, act, noise, seed, stream_id, step, row0=0, pieces=1, row_start=0,
@@ -422,5 +491,5 @@ def visible_site(mode):
     return ACT_SIGMOID, NOISE_BERNOULLI
 
 
-__all__ = ["DeviceRBM", "DeviceMatrix", "resolve_device", "hidden_site", "visible_site", "round_up",
+__all__ = ["DeviceRBM", "DeviceMatrix", "ResidentPlanes", "resolve_device", "device_guard", "hidden_site", "visible_site", "round_up",
            "MODE_VISIBLE_BERNOULLI", "MODE_VISIBLE_GAUSSIAN", "MODE_COMPLEX", "NOISE_NONE"]

@@ -25,7 +25,7 @@ from .. import _lib
 from . import dp
 from .engine import (CHAIN_BH, CHAIN_BV, CHAIN_SCORE, CHAIN_STRIDE, CHAIN_W, MODE_COMPLEX,
                      MODE_VISIBLE_BERNOULLI, MODE_VISIBLE_GAUSSIAN, STREAM_INV_TRANSFORM, STREAM_TRANSFORM,
-                     DeviceMatrix, DeviceRBM, hidden_site, resolve_device, visible_site)
+                     DeviceMatrix, DeviceRBM, device_guard, hidden_site, resolve_device, visible_site)
 
 _UPDATE_MODES = ("fused", "reference_sequential")
 
@@ -76,6 +76,7 @@ class RBM(object):
         self._update_count = 0         # `step` of the RNG contract for fit()
         self._call_count = 0           # `step` of the RNG contract for transform / inv_transform / call
         self._v_chain = None           # persistent fantasy particles
+        self._planes = None            # engine.ResidentPlanes of the data matrix during an x3 fit()
         self.last_scores = []
 
     # ------------------------------------------------------------------ build ----------
@@ -137,21 +138,28 @@ class RBM(object):
         self._dev.set_weights(W, b_h, b_v)
 
     # ------------------------------------------------------------------ forward passes --
+    @staticmethod
+    def _n_cols(x):
+        x = _unwrap(x)
+        return x.cols if isinstance(x, DeviceMatrix) else x.shape[1]
+
     def _as_device(self, x):
+        """(DeviceMatrix, kind): kind = "device" for a DeviceMatrix, the input's torch.device for a tensor, "numpy"."""
         x = _unwrap(x)
         if isinstance(x, DeviceMatrix):
             return x, "device"
-        n_cols = x.shape[1]
-        kind = "torch" if isinstance(x, torch.Tensor) else "numpy"
+        kind = x.device if isinstance(x, torch.Tensor) else "numpy"
         dev = self._dev.device if self._dev is not None else resolve_device(self._device_arg)
-        with torch.cuda.device(dev):
+        with device_guard(dev):
             return DeviceMatrix.from_host(x, dev), kind
 
     def _ret(self, m, kind, as_list):
+        """Results go back where the input came from: a DeviceMatrix as is, a tensor on the input tensor's device,
+        a numpy array on the host (the K.function convention of the reference)."""
         if kind == "device":
             out = m
-        elif kind == "torch":
-            out = m.view()
+        elif isinstance(kind, torch.device):
+            out = m.view().to(kind)
         else:
             out = m.to_numpy()
         return [out] if as_list else out
@@ -180,8 +188,7 @@ class RBM(object):
 
     def transform(self, v):
         """Sampled hidden states of v (transform_func, rbm.py:88-89 -> :46-48 / :58-60)."""
-        n_cols = _unwrap(v).cols if isinstance(_unwrap(v), DeviceMatrix) else _unwrap(v).shape[1]
-        self._ensure_built(n_cols)
+        self._ensure_built(self._n_cols(v))
         x, kind = self._as_device(v)
         return self._ret(self._sample_hidden(x), kind, self.list_returns and kind != "device")
 
@@ -194,8 +201,7 @@ class RBM(object):
 
     def call(self, x):
         """The layer's forward pass: stochastic hidden features (rbm.py:80-86)."""
-        n_cols = _unwrap(x).shape[1]
-        self._ensure_built(n_cols)
+        self._ensure_built(self._n_cols(x))
         xd, kind = self._as_device(x)
         return self._ret(self._sample_hidden(xd), kind, False)
 
@@ -203,12 +209,14 @@ class RBM(object):
 
     def cal_free_energy(self, v):
         """F(v) = -(v.b_v + sum_j softplus((v.W + b_h)_j))   (free_energy_func, rbm.py:97-98 -> :73-76)."""
-        n_cols = _unwrap(v).cols if isinstance(_unwrap(v), DeviceMatrix) else _unwrap(v).shape[1]
-        self._ensure_built(n_cols)
+        self._ensure_built(self._n_cols(v))
         x, kind = self._as_device(v)
         F = self._dev.free_energy(x, x.rows, compute="x3" if self._large(x.rows) else None)
-        if kind in ("device", "torch"):
-            return [F] if (self.list_returns and kind != "device") else F
+        if kind == "device":
+            return F
+        if isinstance(kind, torch.device):          # torch input: the result goes back to the input's device
+            F = F.to(kind)
+            return [F] if self.list_returns else F
         F = F.cpu().numpy()
         return [F] if self.list_returns else F
 
@@ -264,6 +272,19 @@ class RBM(object):
             first = min(bs, n)
             self._v_chain.t[:first].copy_(Vd.t[:first])
 
+        # x3: the bf16 planes of every window of rows this fit walks are made once, here (the data is the same every
+        # epoch); the fallback -- not enough HBM -- is the per-step conversion inside the library
+        planes = None
+        if self._compute() == "x3" and n > 0:
+            windows = []
+            for i in range(num_step):
+                lo, rows = i * bs, min((i + 1) * bs, n) - i * bs
+                if world > 1:
+                    s_lo, s_hi = self._shard(rows, rank, world)
+                    lo, rows = lo + s_lo, s_hi - s_lo
+                windows.append((lo, rows))
+            planes = d.make_planes(Vd, windows, self.mode, self._v_chain if self.persistent else None)
+        self._planes = planes
         # quiet single-GPU fused training (fp32 MFMA or x3): the whole batch loop of an epoch is one library call
         whole_epochs = (verbose != 1 and world == 1 and self.update_mode == "fused"
                         and self._compute() in ("fp32", "x3"))
@@ -273,7 +294,7 @@ class RBM(object):
             if whole_epochs:
                 self._update_count += d.cd_epoch(Vd, n, bs, lr, self.seed, self._update_count, k=self.cd_k,
                                                  mode=self.mode, v_chain=self._v_chain if self.persistent else None,
-                                                 compute=self._compute())
+                                                 compute=self._compute(), planes=planes)
                 continue
             for i in range(num_step):                                            # rbm.py:163
                 lo, hi = i * bs, min((i + 1) * bs, n)                            # rbm.py:211 / :218
@@ -282,13 +303,13 @@ class RBM(object):
                 if world == 1:
                     self._update_local(Vd, lo, rows, lr, step)
                 else:
-                    nxt = (hi, min(hi + bs, n) - hi) if i + 1 < num_step else None
-                    self._update_data_parallel(Vd, lo, rows, lr, step, rank, world, nxt)
+                    self._update_data_parallel(Vd, lo, rows, lr, step, rank, world)
                 self._update_count += 1
                 if verbose == 1:
                     score = self._score(Vd, lo, rows, step)
                     self.last_scores.append(score)
                     print("\n{0:d}/{1:d}, score: {2:f}".format(i + 1, num_step, score))   # rbm.py:234
+        self._planes = None
         return None
 
     def _compute(self):
@@ -300,46 +321,29 @@ class RBM(object):
         d = self._dev
         if self.update_mode == "fused":
             d.cd_step(Vd, rows, lo, lr, self.seed, step, k=self.cd_k, mode=self.mode, chain=CHAIN_W,
-                      v_chain=self._v_chain if self.persistent else None, compute=self._compute())
+                      v_chain=self._v_chain if self.persistent else None, compute=self._compute(), planes=self._planes)
         else:
             # the reference's three K.function calls: each its own chain, each seeing the variables
             # the previous call already updated (rbm.py:214-216)
             for chain, which in ((CHAIN_W, _lib.WHICH_W), (CHAIN_BH, _lib.WHICH_BH), (CHAIN_BV, _lib.WHICH_BV)):
                 d.cd_step(Vd, rows, lo, lr, self.seed, step, k=1, mode=self.mode, chain=chain, which=which,
-                          compute=self._compute())
+                          compute=self._compute(), planes=self._planes)
 
-    def _update_data_parallel(self, Vd, lo, rows, lr, step, rank, world, nxt=None):
-        """Each rank: chain on its rows -> packed sums -> one all-reduce -> identical apply.
-        nxt = (row_start, rows) of the next batch: on the x3 path its conversion runs under this step's all-reduce."""
+    def _update_data_parallel(self, Vd, lo, rows, lr, step, rank, world):
+        """Each rank: the chain on its rows of the batch -> packed sums -> sum all-reduce (RCCL, inside libkurbm.so) ->
+        the identical update on every replica.  Philox counters use the row's index in the global batch (row0)."""
         if self.update_mode != "fused":
             raise ValueError("data-parallel training supports update_mode='fused' only")
         d = self._dev
-        s_lo, s_hi = dp.shard_rows(rows, world, rank)
-        delta = d.delta_buffer()
-        if s_hi > s_lo and self._compute() == "x3" and dp.OVERLAP_ROW_RANGES:
-            # chain, then dW in two row ranges: the first all-reduce overlaps the second range's GEMM
-            dp.x3_sums_overlapped(d, Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, row0=s_lo,
-                                  v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo)
-        elif s_hi > s_lo and self._compute() == "x3" and dp.PRECONVERT:
-            if getattr(self, "_dp_pipe", None) is None or self._dp_pipe.eng is not d:
-                self._dp_pipe = dp.X3Pipeline(d)
-            nxt_shard = None
-            if nxt is not None:
-                n_lo, n_hi = dp.shard_rows(nxt[1], world, rank)
-                nxt_shard = (nxt[0] + n_lo, n_hi - n_lo)
-            self._dp_pipe.step(Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, nxt=nxt_shard, k=self.cd_k, mode=self.mode,
-                               chain=CHAIN_W, row0=s_lo, v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo)
-            return
-        else:
-            if s_hi > s_lo:
-                d.cd_step(Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,
-                          chain=CHAIN_W, apply=False, emit_delta=True, row0=s_lo,
-                          v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo,
-                          compute=self._compute())
-            else:
-                delta.zero_()
-            dp.allreduce_sum_(delta)
-        d.apply_delta(lr, compute=self._compute())
+        s_lo, s_hi = self._shard(rows, rank, world)
+        d.cd_step_dp(dp.get_comm(d.device), Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,
+                     chain=CHAIN_W, row0=s_lo, v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo,
+                     compute=self._compute(), planes=self._planes)
+
+    def _shard(self, rows, rank, world):
+        """This rank's rows [lo, hi) of a batch of `rows` rows (persistent chains: fixed ownership of the chain's rows,
+        whatever the batch's row count)."""
+        return dp.shard_rows(rows, world, rank, of=int(self.hps["batch_size"]) if self.persistent else None)
 
     # ------------------------------------------------------------------ config ----------
     def get_config(self):

@@ -26,14 +26,15 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libkurbm.so does not export %s" % name
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
-    assert lib.kurbm_abi_version() == 1
+    assert lib.kurbm_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(_lib.Params) == 40 and _lib.Params.W.offset == 16
     assert C.sizeof(_lib.Rng) == 24 and _lib.Rng.stream_id.offset == 16
-    assert C.sizeof(_lib.CdOpts) == 56 and _lib.CdOpts.delta_out.offset == 16 and _lib.CdOpts.seed.offset == 32
+    assert C.sizeof(_lib.CdOpts) == 72 and _lib.CdOpts.delta_out.offset == 16 and _lib.CdOpts.seed.offset == 32
+    assert _lib.CdOpts.v_planes.offset == 56 and _lib.CdOpts.v_planes_stride.offset == 64
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device failure mode")
@@ -105,4 +106,15 @@ def test_pack_unpack_roundtrip():
     a, b, c = dp.unpack(p, 5, 3)
     assert torch.equal(a, dW) and torch.equal(b, dbh) and torch.equal(c, dbv)
     assert dp.world() == (0, 1)
-    assert dp.allreduce_sum_(p) is None
+
+
+def test_shard_rows_fixed_ownership_for_persistent_chains():
+    """of=batch_size: row j of the fantasy particles stays on one rank in full and remainder batches alike."""
+    for bs, world in ((40, 2), (4096, 8), (100, 3)):
+        full = [dp.shard_rows(bs, world, r, of=bs) for r in range(world)]
+        assert full == [dp.shard_rows(bs, world, r) for r in range(world)]
+        for n in (1, bs // 3, bs // 2 + 1, bs - 1):
+            part = [dp.shard_rows(n, world, r, of=bs) for r in range(world)]
+            for (lo, hi), (flo, fhi) in zip(part, full):
+                assert lo == min(flo, n) and hi == min(fhi, n)
+            assert part[0][0] == 0 and max(hi for _, hi in part) == n

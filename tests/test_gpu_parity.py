@@ -26,6 +26,22 @@ def _engine(W, b_h, b_v, device):
     return DeviceRBM(W, b_h, b_v, device)
 
 
+@pytest.fixture
+def ctx_option(gpu_device):
+    """Set experiment knobs on the device's context for one test (kurbm_ctx_set_option); restored afterwards."""
+    from keras_unsupervised_amd._lib import Context
+    ctx = Context.get(gpu_device.index)
+    touched = {}
+
+    def set_option(name, value, default):
+        touched[name] = default
+        ctx.set_option(name, value)
+
+    yield set_option
+    for name, default in touched.items():
+        ctx.set_option(name, default)
+
+
 def _dm(x, device):
     from keras_unsupervised_amd.ebm.engine import DeviceMatrix
     return DeviceMatrix.from_host(x, device)
@@ -136,7 +152,7 @@ def test_gaussian_mode_half_steps(gpu_device):
     out = e.half_step("hv", out["sample"], 33, 0, 2, 2, 3, 1, 1, want_prob=True)
     loc, z, v1 = O.sample_visible(h, W, b_v, rng, 1, O.MODE_VISIBLE_GAUSSIAN)
     assert np.max(np.abs(out["prob"].to_numpy() - loc)) <= TOL
-    assert np.max(np.abs(out["sample"].to_numpy() - v1)) <= 5e-4   # Box-Muller in fp32: log/cos rounding
+    assert np.max(np.abs(out["sample"].to_numpy() - v1)) <= TOL    # loc + Box-Muller(u_a, u_b), both sides in fp32
     assert abs(float(z.mean())) < 0.1
 
 
@@ -229,10 +245,11 @@ def test_cd_step_vs_oracle(gpu_device, cfg):
     d1 = _gpu_cd_delta(e, vd, B, 0.05, 77, 9, k=k, mode=mode, v_chain=cd)
     _, _, _, ch, (dW_ref, dbh_ref, dbv_ref) = O.cd_step_fused(W, b_h, b_v, v, 0.05, 77, 9, k=k, mode=mode, v_chain=chain0)
     dW, dbh, dbv = _split(d1, nv, nh)
-    tol = 5e-4 if gauss else TOL
-    assert rel_err(dW, dW_ref) <= tol
-    assert rel_err(dbh, dbh_ref) <= tol
-    assert rel_err(dbv, dbv_ref) <= tol
+    if gauss:   # real-valued sums: reference in float64 (numpy's own fp32 matmul / sum error is of the order of the bar)
+        dW_ref, dbh_ref, dbv_ref = O.cd_statistics({k_: ch[k_].astype(np.float64) for k_ in ("v_pos", "h_pos", "v_neg", "h_neg")})
+    assert rel_err(dW, dW_ref) <= TOL
+    assert rel_err(dbh, dbh_ref) <= TOL
+    assert rel_err(dbv, dbv_ref) <= TOL
     if cd is not None:   # the chain buffer now holds v_neg
         assert np.array_equal(cd.to_numpy(), ch["v_neg"])
         cd = _dm(chain0, gpu_device)
@@ -388,6 +405,19 @@ def test_checkpoint_round_trip(gpu_device, tmp_path):
     b.fit(V, verbose=0)
     assert np.array_equal(a.rbm_weight, b.rbm_weight)    # same counters -> same draws -> same bits
     assert np.array_equal(a.transform(V)[0], b.transform(V)[0])
+    # persistent chains: the fantasy particles travel with the checkpoint, so the reloaded run continues the SAME chain
+    for compute in ("fp32", "x3"):
+        pa = RBM(hps, nh, name="pcd", mode=MODE_VISIBLE_BERNOULLI, seed=3, persistent=True, compute_dtype=compute,
+                 weights=synthetic_params(nv, nh, 71))
+        pa.fit(V, verbose=0)
+        save_rbm(pa, str(tmp_path / "pcd"))
+        pb = load_rbm(str(tmp_path / "pcd"))
+        assert pb.persistent and np.array_equal(pb._v_chain.to_numpy(), pa._v_chain.to_numpy())
+        pa.fit(V, verbose=0)
+        pb.fit(V, verbose=0)
+        assert np.array_equal(pa.rbm_weight, pb.rbm_weight)
+        fresh = RBM(hps, nh, mode=MODE_VISIBLE_BERNOULLI, seed=3, persistent=True, compute_dtype=compute, weights=pb.get_weights())
+        assert fresh._v_chain is None
     d = DBN()
     d.add_stack(a)
     d.add_stack(RBM(hps, 8, name="top", mode=MODE_VISIBLE_BERNOULLI, seed=4, weights=synthetic_params(nh, 8, 72)))
@@ -484,25 +514,38 @@ def test_bf16_rbm_fit(gpu_device):
     assert not np.array_equal(a.rbm_weight, b.rbm_weight)
 
 
-@pytest.mark.parametrize("pipe", ["0", "1"])
-@pytest.mark.parametrize("shape", [(150, 64, 72, 40, 2), (1400, 256, 200, 136, 1), (512, 256, 784, 64, 1)])
-def test_x3_epoch_call_equals_step_loop(gpu_device, monkeypatch, pipe, shape):
-    """kurbm_cd_epoch_x3 (one call per epoch) and the per-step host loop give bit-identical parameters -- also with
-    KURBM_X3_PIPE=1, where batch t+1 is converted on a side stream into a second set of planes while step t runs
-    (two calls in a row: the second epoch starts on the planes the first one left)."""
-    N, bs, nv, nh, k = shape
-    monkeypatch.setenv("KURBM_X3_PIPE", pipe)
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("shape", [(150, 64, 72, 40, 2, False), (1400, 256, 200, 136, 1, False), (512, 256, 784, 64, 1, False),
+                                   (700, 256, 200, 136, 1, True)])
+def test_x3_epoch_call_equals_step_loop(gpu_device, resident, shape):
+    """kurbm_cd_epoch_x3 (one call per epoch) and the per-step host loop give bit-identical parameters -- with the
+    per-step conversion of the batch and with RESIDENT planes (kurbm_x3_convert_rows once per window of rows, every step
+    of every epoch reading them through opts->v_planes: the k_f32_to_bf16 launch is gone from the loop), for 0/1 data
+    (one piece) and real-valued data (three), remainder batch included."""
+    N, bs, nv, nh, k, real = shape
     W0 = synthetic_params(nv, nh, seed=700)
-    V = synthetic_binary(N, nv, seed=701, p=0.3)
+    V = synthetic_real(N, nv, seed=701) if real else synthetic_binary(N, nv, seed=701, p=0.3)
     a, b = _engine(*W0, gpu_device), _engine(*W0, gpu_device)
     vd = _dm(V, gpu_device)
-    nsteps = len(O.batch_slices(N, bs))
+    slices = O.batch_slices(N, bs)
+    nsteps = len(slices)
+    planes = a.make_planes(vd, [(lo, hi - lo) for lo, hi in slices]) if resident else None
+    assert (planes is not None) == resident
+    if resident:
+        assert planes.uniform(0, N, bs) and planes.v_pieces == (3 if real else 1)
     for epoch in range(2):
-        assert a.cd_epoch(vd, N, bs, 0.01, 9, 5 + epoch * nsteps, k=k, compute="x3") == nsteps
-        for i, (lo, hi) in enumerate(O.batch_slices(N, bs)):
+        assert a.cd_epoch(vd, N, bs, 0.01, 9, 5 + epoch * nsteps, k=k, compute="x3", planes=planes) == nsteps
+        for i, (lo, hi) in enumerate(slices):
             b.cd_step(vd, hi - lo, lo, 0.01, 9, 5 + epoch * nsteps + i, k=k, compute="x3")
     for x, y in zip(a.get_weights(), b.get_weights()):
         assert np.array_equal(x, y)
+    if resident:   # and step by step on the same planes
+        c = _engine(*W0, gpu_device)
+        for epoch in range(2):
+            for i, (lo, hi) in enumerate(slices):
+                c.cd_step(vd, hi - lo, lo, 0.01, 9, 5 + epoch * nsteps + i, k=k, compute="x3", planes=planes)
+        for x, y in zip(c.get_weights(), b.get_weights()):
+            assert np.array_equal(x, y)
 
 
 def test_epoch_call_equals_step_loop(gpu_device):
@@ -712,23 +755,92 @@ def test_x3_rbm_fit_trajectory_golden(gpu_device, golden_dir):
         assert np.max(np.abs(r.visible_bias - g["bv_" + um])) <= TOL
 
 
-def test_x3_overlapped_dp_sums_equal_one_shot(gpu_device):
-    """dp.x3_sums_overlapped (chain, then dW in two row ranges) leaves the same packed sums as one
-    kurbm_cd_step_x3(apply=0): draws identical, sums equal up to the order of the fp32 additions."""
+@pytest.fixture(scope="module")
+def one_rank_comm(gpu_device):
+    """A 1-rank RCCL communicator through the C ABI (kurbm_comm_unique_id / kurbm_comm_init_rank): what a one-GPU box can
+    exercise of the exchange step -- RCCL bound and called from inside libkurbm.so, the comm stream, the events."""
     from keras_unsupervised_amd.ebm import dp
-    for (B, nv, nh, k) in ((300, 784, 256, 1), (260, 300, 200, 2), (64, 100, 80, 1)):
-        W0 = synthetic_params(nv, nh, seed=1100 + B)
-        V = synthetic_binary(B, nv, seed=1101 + B, p=0.3)
+    comm = dp.Comm(gpu_device, 0, 1, dp.Comm.new_unique_id())
+    yield comm
+    comm.destroy()
+
+
+def test_comm_through_c_abi(gpu_device, one_rank_comm):
+    comm = one_rank_comm
+    assert comm.count() == 1                                   # ncclCommCount
+    assert comm.lib.kurbm_comm_rank(comm.handle) == 0          # ncclCommUserRank
+    x = torch.randn(804624, device=gpu_device)                 # the packed [dW | db_h | db_v] of 784 x 1024
+    y = x.clone()
+    comm.allreduce_sum_(y)
+    comm.barrier()
+    assert torch.equal(x, y)                                   # a sum over one rank
+    from keras_unsupervised_amd import _lib
+    with pytest.raises(_lib.KurbmError):                       # a null communicator is an error code, not a fault
+        _lib.check(comm.lib.kurbm_allreduce_sum_f32(None, y.data_ptr(), 4, None))
+
+
+@pytest.mark.parametrize("cfg", [dict(B=300, nv=784, nh=256, k=1), dict(B=260, nv=1100, nh=200, k=2, pcd=True),
+                                 dict(B=64, nv=100, nh=80, k=1), dict(B=256, nv=640, nh=136, k=1, gauss=True),
+                                 dict(B=4096, nv=784, nh=1024, k=1)])
+def test_x3_dp_step_one_call(gpu_device, one_rank_comm, cfg):
+    """kurbm_cd_step_x3_dp -- chain, statistics in row ranges of dW with each range all-reduced on the library's comm
+    stream while the next is computed, fused apply + weight-piece mirror -- against the plain sequence
+    emit -> all-reduce -> apply: bit-identical with one range, within fp32 summation order with several (the split-K
+    slicing of a row range differs); Gaussian mode (the reference's default) included; a rank without rows joins with
+    zeros and leaves the parameters where they were."""
+    B, nv, nh, k = cfg["B"], cfg["nv"], cfg["nh"], cfg["k"]
+    mode = O.MODE_VISIBLE_GAUSSIAN if cfg.get("gauss") else O.MODE_VISIBLE_BERNOULLI
+    W0 = synthetic_params(nv, nh, seed=1100 + B)
+    V = synthetic_real(B, nv, seed=1101 + B) if cfg.get("gauss") else synthetic_binary(B, nv, seed=1101 + B, p=0.3)
+    chain0 = synthetic_binary(B, nv, seed=1102 + B, p=0.5) if cfg.get("pcd") else None
+    vd = _dm(V, gpu_device)
+    ref = _engine(*W0, gpu_device)
+    cr = _dm(chain0, gpu_device) if chain0 is not None else None
+    ref.cd_step(vd, B, 0, 0.01, 5, 3, k=k, mode=mode, apply=False, emit_delta=True, row0=8, v_chain=cr, compute="x3")
+    d_ref = ref.delta_buffer().clone()
+    ref.apply_delta(0.01, compute="x3")
+    for n_chunks in (1, 2, 3, 0):
         e = _engine(*W0, gpu_device)
-        vd = _dm(V, gpu_device)
-        ref = _gpu_cd_delta(e, vd, B, 0.01, 5, 3, k=k, compute="x3")
-        dp.x3_sums_overlapped(e, vd, B, 0, 0.01, 5, 3, k=k)
+        cd = _dm(chain0, gpu_device) if chain0 is not None else None
+        e.cd_step_dp(one_rank_comm, vd, B, 0, 0.01, 5, 3, k=k, mode=mode, row0=8, v_chain=cd, compute="x3", n_chunks=n_chunks)
         torch.cuda.synchronize()
-        got = e.delta_buffer().cpu().numpy()
-        dW, dbh, dbv = _split(got, nv, nh)
-        rW, rbh, rbv = _split(ref, nv, nh)
-        assert np.max(np.abs(dW - rW)) <= 1e-4 * max(1.0, float(np.abs(rW).max()))
-        assert np.array_equal(dbv, rbv) and np.allclose(dbh, rbh, rtol=0, atol=1e-4 * max(1.0, float(np.abs(rbh).max())))
+        if cd is not None:
+            assert np.array_equal(cd.to_numpy(), cr.to_numpy())
+        got, want = e.delta_buffer().cpu().numpy(), d_ref.cpu().numpy()
+        if n_chunks == 1:
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            for x, y in zip(e.get_weights(), ref.get_weights()):
+                assert np.array_equal(x, y)
+        else:
+            dW, dbh, dbv = _split(got, nv, nh)
+            rW, rbh, rbv = _split(want, nv, nh)
+            assert np.max(np.abs(dW - rW)) <= 1e-4 * max(1.0, float(np.abs(rW).max()))
+            assert np.array_equal(dbv.view(np.uint32), rbv.view(np.uint32)) and np.array_equal(dbh.view(np.uint32), rbh.view(np.uint32))
+            for x, y in zip(e.get_weights(), ref.get_weights()):
+                assert np.max(np.abs(x - y)) <= 1e-6 * max(1.0, float(np.abs(y).max()))    # a few ulp: other split-K slicing
+        # the rewritten weight pieces are the new weights
+        p1 = e.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=3)["prob"].to_numpy()
+        assert np.max(np.abs(p1 - O.hidden_prob(V, *e.get_weights()[:2]))) <= TOL
+    # a rank that owns no rows of the batch
+    e = _engine(*W0, gpu_device)
+    e.cd_step_dp(one_rank_comm, vd, 0, 0, 0.01, 5, 3, k=k, mode=mode, compute="x3")
+    torch.cuda.synchronize()
+    assert float(e.delta_buffer().abs().max().item()) == 0.0
+    for x, y in zip(e.get_weights(), W0):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_dp_step_other_paths(gpu_device, one_rank_comm, compute):
+    """The data-parallel step of the fp32-MFMA and rounded-bf16 paths (emit -> kurbm_allreduce_sum_f32 -> apply)."""
+    B, nv, nh = 200, 300, 140
+    W0 = synthetic_params(nv, nh, seed=1200)
+    vd = _dm(synthetic_binary(B, nv, seed=1201, p=0.3), gpu_device)
+    a, b = _engine(*W0, gpu_device), _engine(*W0, gpu_device)
+    a.cd_step_dp(one_rank_comm, vd, B, 0, 0.01, 5, 3, k=2, row0=4, compute=compute)
+    b.cd_step(vd, B, 0, 0.01, 5, 3, k=2, row0=4, compute=compute)
+    for x, y in zip(a.get_weights(), b.get_weights()):
+        assert np.max(np.abs(x - y)) <= 1e-6
 
 
 def test_x3_random_shape_sweep(gpu_device):
@@ -803,15 +915,15 @@ def test_x3_transform_surface(gpu_device):
     Ha, Hb = a.transform(Vr)[0], b.transform(Vr)[0]
     assert (Ha != Hb).sum() <= 8
     Va, Vb = a.inv_transform(Ha)[0], b.inv_transform(Ha)[0]
-    assert np.max(np.abs(Va - Vb)) <= 5e-4
+    assert np.max(np.abs(Va - Vb)) <= TOL
 
 
 @pytest.mark.parametrize("cfg", [dict(B=30, nv=52, nh=44, k=1), dict(B=200, nv=300, nh=140, k=2),
                                  dict(B=130, nv=96, nh=260, k=1, pcd=True), dict(B=512, nv=784, nh=256, k=1)])
 def test_x3_gaussian_visibles_vs_oracle(gpu_device, cfg):
     """MODE_VISIBLE_GAUSSIAN on the x3 path: the negative visibles are real-valued and travel as three exact pieces
-    (row-major for the next half step, transposed for the statistics).  Same oracle, same bar as the fp32 MFMA
-    Gaussian test (5e-4: Box-Muller's log / cos in fp32)."""
+    (row-major for the next half step, transposed for the statistics).  Same oracle, same 1e-4 bar as everything else;
+    the real-valued sums are compared with float64 statistics of the oracle's chain states."""
     B, nv, nh, k = cfg["B"], cfg["nv"], cfg["nh"], cfg["k"]
     mode = O.MODE_VISIBLE_GAUSSIAN
     W, b_h, b_v = synthetic_params(nv, nh, seed=1400 + B)
@@ -823,20 +935,21 @@ def test_x3_gaussian_visibles_vs_oracle(gpu_device, cfg):
     d1 = _gpu_cd_delta(e, vd, B, 0.01, 77, 9, k=k, mode=mode, v_chain=cd, compute="x3")
     _, _, _, ch, (dW_ref, dbh_ref, dbv_ref) = O.cd_step_fused(W, b_h, b_v, v, 0.01, 77, 9, k=k, mode=mode, v_chain=chain0)
     dW, dbh, dbv = _split(d1, nv, nh)
-    assert rel_err(dW, dW_ref) <= 5e-4 and rel_err(dbh, dbh_ref) <= 5e-4 and rel_err(dbv, dbv_ref) <= 5e-4
+    dW_ref, dbh_ref, dbv_ref = O.cd_statistics({k_: ch[k_].astype(np.float64) for k_ in ("v_pos", "h_pos", "v_neg", "h_neg")})
+    assert rel_err(dW, dW_ref) <= TOL and rel_err(dbh, dbh_ref) <= TOL and rel_err(dbv, dbv_ref) <= TOL
     if cd is not None:
-        assert np.max(np.abs(cd.to_numpy() - ch["v_neg"])) <= 5e-4
+        assert np.max(np.abs(cd.to_numpy() - ch["v_neg"])) <= TOL
         cd = _dm(chain0, gpu_device)
     d2 = _gpu_cd_delta(e, vd, B, 0.01, 77, 9, k=k, mode=mode, v_chain=cd, compute="x3")
     assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
     # against the fp32 MFMA kernels on the same counters
     d32 = _gpu_cd_delta(e, vd, B, 0.01, 77, 9, k=k, mode=mode, v_chain=_dm(chain0, gpu_device) if chain0 is not None else None)
-    assert rel_err(d1[: nv * nh], d32[: nv * nh]) <= 5e-4
+    assert rel_err(d1[: nv * nh], d32[: nv * nh]) <= TOL
     # half step hook: h -> v with N(loc, 1) noise
     h = synthetic_binary(B, nh, seed=1403 + B, p=0.5)
     out = e.half_step_bf16("hv", _dm(h, gpu_device), B, 2, 2, 3, 1, 1, pieces=3)
     loc, z, v1 = O.sample_visible(h, W, b_v, O.Rng(3, 1), 1, mode)
-    assert np.max(np.abs(out["prob"].to_numpy() - loc)) <= TOL and np.max(np.abs(out["sample"].to_numpy() - v1)) <= 5e-4
+    assert np.max(np.abs(out["prob"].to_numpy() - loc)) <= TOL and np.max(np.abs(out["sample"].to_numpy() - v1)) <= TOL
 
 
 @pytest.mark.parametrize("shape", [(6, 64, 48), (150, 300, 200), (1024, 784, 1024), (1100, 130, 257)])
@@ -934,41 +1047,15 @@ def test_step_does_not_read_uninitialised_workspace(gpu_device, compute, shape):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("cfg", [dict(B=256, nv=200, nh=136, k=1, mode="bernoulli"), dict(B=512, nv=784, nh=64, k=2, mode="gaussian")])
-def test_x3_dp_preconvert_equals_plain_sequence(gpu_device, cfg):
-    """dp.X3Pipeline (the next batch converted while this step's all-reduce is in flight; a step then starts at stage 9 on
-    the planes already in the workspace) leaves the bits of the plain sequence emit -> all-reduce -> apply.  Ragged tail:
-    the last batch has another row count and is not pre-converted."""
-    from keras_unsupervised_amd.ebm import dp
-    B, nv, nh, k = cfg["B"], cfg["nv"], cfg["nh"], cfg["k"]
-    mode = O.MODE_VISIBLE_GAUSSIAN if cfg["mode"] == "gaussian" else O.MODE_VISIBLE_BERNOULLI
-    N = 4 * B + 70
-    W0 = synthetic_params(nv, nh, seed=1900)
-    V = synthetic_real(N, nv, seed=1901) if cfg["mode"] == "gaussian" else synthetic_binary(N, nv, seed=1901, p=0.3)
-    a, b = _engine(*W0, gpu_device), _engine(*W0, gpu_device)
-    va, vb = _dm(V, gpu_device), _dm(V, gpu_device)
-    slices = O.batch_slices(N, B)
-    pipe = dp.X3Pipeline(a)
-    for epoch in range(2):
-        for i, (lo, hi) in enumerate(slices):
-            step = epoch * len(slices) + i
-            nxt = (slices[i + 1][0], slices[i + 1][1] - slices[i + 1][0]) if i + 1 < len(slices) else None
-            pipe.step(va, hi - lo, lo, 0.01, 9, step, nxt=nxt, k=k, mode=mode, row0=lo)
-            b.cd_step(vb, hi - lo, lo, 0.01, 9, step, k=k, mode=mode, apply=False, emit_delta=True, row0=lo, compute="x3")
-            b.apply_delta(0.01, compute="x3")
-    for x, y in zip(a.get_weights(), b.get_weights()):
-        assert np.array_equal(x, y)
-
-
 @pytest.mark.parametrize("tall", ["0", "1"])
 @pytest.mark.parametrize("shape", [(256, 64, 64), (512, 100, 500), (1024, 784, 200), (768, 200, 136), (2048, 130, 1024),
-                                   (1300, 784, 257), (4096, 1024, 784)])
-def test_x3_half_steps_tile_configs(gpu_device, monkeypatch, tall, shape):
+                                   (1300, 784, 257), (4096, 1024, 784), (4096, 784, 1024)])
+def test_x3_half_steps_tile_configs(gpu_device, ctx_option, tall, shape):
     """The x3 half steps on forced 128 x 128 and forced 256 x 64 tiles (KURBM_X3_TALL; the tall kernels need an even number
     of 128-row tiles and are skipped otherwise), with whatever XCD block factorisation the grid admits: probabilities and
     draws against the oracle, row-major and transposed planes through a second half step on the output."""
     B, nv, nh = shape
-    monkeypatch.setenv("KURBM_X3_TALL", tall)
+    ctx_option("KURBM_X3_TALL", int(tall), -1)
     W, b_h, b_v = synthetic_params(nv, nh, seed=2000 + B)
     e = _engine(W, b_h, b_v, gpu_device)
     rng = O.Rng(5, 3)
