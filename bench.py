@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip paths.* beyond x3 / fp32 (real-valued data, Gaussian mode): they launch the SAME kernels with more "
+                         "segments, which would blur a rocprofv3 --stats average of the config-2 launches (tools/profile_round.sh)")
     ap.add_argument("--compute", choices=("x3", "fp32"), default=os.environ.get("BENCH_COMPUTE", "x3"))
     args = ap.parse_args()
 
@@ -102,6 +105,9 @@ def main():
     V = DeviceMatrix((u.t < 0.19).to(torch.float32).contiguous(), n_batches * BATCH, N_VIS, u.ld)
     lr = 1e-3 / BATCH            # keeps the weights finite over long runs; throughput does not depend on lr
     seed = 42
+    # what RBM.fit does once per call on the x3 path: the bf16 planes of every batch window of the resident data matrix
+    # (kurbm_x3_convert_rows); the steps then read them instead of converting their 4096 rows again every epoch
+    planes = eng.make_planes(V, [(i * BATCH, BATCH) for i in range(n_batches)]) if args.compute == "x3" else None
 
     # BENCH_FORCE_DP=1 runs the data-parallel step (1-rank RCCL communicator) on a single-GPU box: a rehearsal of the N > 1 path
     use_dp = world > 1 or os.environ.get("BENCH_FORCE_DP", "0") == "1"
@@ -113,9 +119,9 @@ def main():
     def step(i):
         lo = (i % n_batches) * BATCH
         if comm is None:
-            eng.cd_step(V, BATCH, lo, lr, seed, i, compute=args.compute)
+            eng.cd_step(V, BATCH, lo, lr, seed, i, compute=args.compute, planes=planes)
         else:
-            eng.cd_step_dp(comm, V, BATCH, lo, lr, seed, i, row0=rank * BATCH, compute=args.compute)
+            eng.cd_step_dp(comm, V, BATCH, lo, lr, seed, i, row0=rank * BATCH, compute=args.compute, planes=planes)
 
     def fence():
         if comm is not None:
@@ -204,19 +210,23 @@ def main():
                 r["executed_bf16_tflops"] = units * BVH2 / (ms * 1e-3) / 1e12
                 r["executed_frac_of_bf16_peak"] = r["executed_bf16_tflops"] / PEAK_BF16_MFMA_TFLOPS
             return r
-        paths = {"x3": path(lambda: eng.cd_step(V, BATCH, 0, lr, seed, 0, compute="x3"), X3_UNITS["binary"]),
+        pl1 = planes if planes is not None else eng.make_planes(V, [(0, BATCH)])
+        paths = {"x3": path(lambda: eng.cd_step(V, BATCH, 0, lr, seed, 0, compute="x3", planes=pl1), X3_UNITS["binary"]),
+                 "x3_convert_per_step": path(lambda: eng.cd_step(V, BATCH, 0, lr, seed, 0, compute="x3"), X3_UNITS["binary"]),
                  "fp32": path(lambda: eng.cd_step(V, BATCH, 0, lr, seed, 0, compute="fp32"))}
         # grey-level data (k / 255, not bf16-exact: the batch travels as three pieces), Bernoulli mode and the
         # reference's default Gaussian-visible mode (rbm.py:22; relu thresholds, N(loc, 1) visibles)
-        ug = eng.philox_uniform(BATCH, N_VIS, 99, 0x7005, 0)
-        Vg = DeviceMatrix((torch.floor(ug.t * 256.0) / 255.0).contiguous(), BATCH, N_VIS, ug.ld)
-        paths["x3_real_valued"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, compute="x3"), X3_UNITS["real"])
-        paths["fp32_real_valued"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, compute="fp32"))
-        Wkeep = eng.get_weights()
-        paths["gaussian_default_mode"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, mode=MODE_VISIBLE_GAUSSIAN, compute="x3"),
-                                              X3_UNITS["gaussian_real"])
-        paths["gaussian_default_mode_fp32"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, mode=MODE_VISIBLE_GAUSSIAN, compute="fp32"))
-        eng.set_weights(*Wkeep)
+        if not args.no_variants:
+            ug = eng.philox_uniform(BATCH, N_VIS, 99, 0x7005, 0)
+            Vg = DeviceMatrix((torch.floor(ug.t * 256.0) / 255.0).contiguous(), BATCH, N_VIS, ug.ld)
+            plg = eng.make_planes(Vg, [(0, BATCH)])
+            paths["x3_real_valued"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, compute="x3", planes=plg), X3_UNITS["real"])
+            paths["fp32_real_valued"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, compute="fp32"))
+            Wkeep = eng.get_weights()
+            paths["gaussian_default_mode"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, mode=MODE_VISIBLE_GAUSSIAN, compute="x3",
+                                                                      planes=plg), X3_UNITS["gaussian_real"])
+            paths["gaussian_default_mode_fp32"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, mode=MODE_VISIBLE_GAUSSIAN, compute="fp32"))
+            eng.set_weights(*Wkeep)
         traffic_all, traffic_file = {}, None
         try:
             import glob
@@ -259,7 +269,9 @@ def main():
                        "n_vis": N_VIS, "n_hid": N_HID, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "cd_k": 1, "update_mode": "fused", "lr": "1e-3/4096", "parallelism": "dp%d" % world,
                        "compute": args.compute, "flop_per_step": FLOP_STEP,
-                       "data_parallel_step": None if comm is None else "kurbm_cd_step_x3_dp (RCCL all-reduce inside libkurbm.so, 2 row ranges)",
+                       "data_planes": None if planes is None else "resident: bf16 planes of the 16 batch windows made once before the warm-up "
+                                      "(%.0f MB), as RBM.fit does once per call; paths.x3_convert_per_step converts the batch in every step" % (planes.buf.numel() / 1e6),
+                       "data_parallel_step": None if comm is None else "kurbm_cd_step_x3_dp (RCCL all-reduce inside libkurbm.so; row ranges: KURBM_DP_CHUNKS, default one)",
                        "timing": {"blocks": repeats, "steps_per_block": args.steps,
                                   "value": "N x K / median block time; W = %d untimed warm-up steps before the first block" % args.warmup,
                                   "value_first_block": "first block alone (cold clocks)",

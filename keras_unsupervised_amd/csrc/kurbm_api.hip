@@ -19,21 +19,18 @@ using namespace kurbm;
 // Experiment knobs.  Every one is read from the environment ONCE, at kurbm_ctx_create, into the context (no getenv on
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
-enum { KN_LDPAD, KN_X3_BN, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_SEGMENTS, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_BF16_CFG, KN_X3_STATS_BM, KN_COUNT };
+enum { KN_LDPAD, KN_X3_BN, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
+       KN_UNFUSED_MIRROR, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
     {"KURBM_X3_BN", 128},          // 64: 128 x 64 x3 tiles, two workgroups per CU
     {"KURBM_BF16_SPLIT", KN_AUTO}, // split-K slices of the bf16 / x3 statistics GEMM
     {"KURBM_X3_FULL", 0},          // 1: all nine piece pairs of a real x real product
-    {"KURBM_X3_SEGMENTS", 0},      // 1: x3 pieces as consecutive k ranges on the rounded-bf16 kernel
     {"KURBM_X3_TALL", KN_AUTO},    // 0 / 1: never / always 256 x 64 half-step tiles
     {"KURBM_X3_MFAST", 1},         // block order of the x3 half steps
     {"KURBM_X3_STATS_MFAST", 0},   // block order of the x3 statistics GEMM
     {"KURBM_UNFUSED_MIRROR", 0},   // 1: slab reduce and weight-piece mirror as two launches
-    {"KURBM_BF16_CFG", KN_AUTO},   // tile configuration of the rounded-bf16 kernel
-    {"KURBM_X3_STATS_BM", KN_AUTO},// row-tile height of the x3 statistics GEMM (128 / 112)
 };
 
 struct kurbm_ctx {
@@ -596,22 +593,22 @@ struct WorkspaceB {
 
 struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_split, ld_slab; };
 
-// pb: the statistics run on k_gemm_pb (x3): k-tile 64, one workgroup per CU, nseg segments walked
-// fastest, so a slice is a whole number of k positions
-static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, bool pb, int s_max = 1 << 30) {
+// the statistics GEMM on k_gemm_pb: k-tile 64, one workgroup per CU, nseg segments walked fastest, so a slice is a whole
+// number of k positions
+static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, int s_max = 1 << 30) {
     OuterPlanB pl;
-    const bool bn64 = pb && ctx->knob[KN_X3_BN] == 64;
+    const bool bn64 = ctx->knob[KN_X3_BN] == 64;
     pl.gm = ceil_div(n_vis, 128);
     pl.gn = ceil_div(n_hid, bn64 ? 64 : 128);
-    pl.nkt = round_up(rows, 128) / (pb ? 64 : 128);
+    pl.nkt = round_up(rows, 128) / 64;
     pl.kt_total = nseg * pl.nkt;
-    int s = ctx->knob[KN_BF16_SPLIT] != KN_AUTO ? ctx->knob[KN_BF16_SPLIT] : ((pb && !bn64 ? 1 : 2) * ctx->ncu) / (pl.gm * pl.gn);
+    int s = ctx->knob[KN_BF16_SPLIT] != KN_AUTO ? ctx->knob[KN_BF16_SPLIT] : ((bn64 ? 2 : 1) * ctx->ncu) / (pl.gm * pl.gn);
     if (s > s_max) s = s_max;
     if (s < 1) s = 1;
     if (s > pl.nkt) s = pl.nkt;
     pl.nsplit_bound = s;
     pl.kt_per_split = ceil_div(pl.kt_total, s);
-    if (pb) pl.kt_per_split = round_up(pl.kt_per_split, nseg);
+    pl.kt_per_split = round_up(pl.kt_per_split, nseg);
     pl.nsplit = ceil_div(pl.kt_total, pl.kt_per_split);
     pl.ld_slab = round_up(n_hid, 4);
     return pl;
@@ -642,7 +639,7 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.planeV = (size_t)w.Kb * w.Lv;
     w.planeVT = (size_t)n_vis * w.Lb;
     w.planeHT = (size_t)n_hid * w.Lb;
-    const OuterPlanB pl = plan_outer_bf16(ctx, rows, n_vis, n_hid, pieces == 3 ? v_pieces + 1 : 2, pieces == 3);
+    const OuterPlanB pl = plan_outer_bf16(ctx, rows, n_vis, n_hid, pieces == 3 ? v_pieces + 1 : 2);
     w.slab_stride = (size_t)n_vis * pl.ld_slab;
     char* b = static_cast<char*>(base);
     size_t off = 0;
@@ -686,20 +683,6 @@ static VPlanes carve_vplanes(const kurbm_ctx* ctx, const void* base, int rows, i
 
 static inline uint32_t inv_of(int nkt) { return nkt > 1 ? (uint32_t)(0x100000000ull / (unsigned)nkt) + 1u : 0u; }
 
-// segment list of a product (a_pieces of A) x (b_pieces of B): all pairs when one side is a single
-// piece; otherwise the pairs with ia + ib <= 2 (the dropped ones are below 2^-24 of the product),
-// or all nine with KURBM_X3_FULL=1
-static int pair_codes(const kurbm_ctx* ctx, int a_pieces, int b_pieces, unsigned set, unsigned long long* codes, int nseg) {
-    const int maxsum = (a_pieces > 1 && b_pieces > 1 && !ctx->knob[KN_X3_FULL]) ? 2 : 4;
-    for (int ia = 0; ia < a_pieces; ++ia)
-        for (int ib = 0; ib < b_pieces; ++ib)
-            if (ia + ib <= maxsum) {
-                *codes |= (unsigned long long)((unsigned)ia | ((unsigned)ib << 2) | (set << 4)) << (5 * nseg);
-                ++nseg;
-            }
-    return nseg;
-}
-
 // optional outputs and side products of a bf16 half step
 struct HalfOutB {
     uint16_t* out = nullptr; int ldo = 0;                 // bf16 value plane, row-major
@@ -707,8 +690,6 @@ struct HalfOutB {
     uint16_t* outT = nullptr; int ldoT = 0;               // ... transposed
     int outT_pieces = 1; size_t outT_plane = 0;
     float* out_f32 = nullptr; float* prob_f32 = nullptr; float* out_u = nullptr; int ldo32 = 0;
-    const float* ref32 = nullptr; int ldref32 = 0;        // column partials of (ref - value)
-    const uint16_t* ref16 = nullptr; int ldref16 = 0;
     float* colpart = nullptr; int ld_colpart = 0;
     float colsign = 1.f;                                  // x3: colpart = colsign * column sums of the value plane
     int* grid_m_out = nullptr;
@@ -724,9 +705,10 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
     g.A0 = A; g.lda = lda; g.a_plane0 = a_plane;
     g.B0 = vh ? m.Wtb : m.Wb; g.ldb = vh ? m.ldWt : m.ldW; g.b_plane0 = vh ? m.planeWt : m.planeW;
     g.M = rows; g.N = vh ? p->n_hid : p->n_vis; g.K = vh ? m.Kv : m.Kh;
-    if (m.pieces == 3 && !ctx->knob[KN_X3_SEGMENTS]) {
-        // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip), 128 x 128 tiles
-        g.nseg = pb_codes(ctx, a_pieces, 3, 0u, &g.seg_codes, 0);
+    {
+        // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip); rounded bf16: against its one piece
+        g.nseg = pb_codes(ctx, a_pieces, m.pieces, 0u, &g.seg_codes, 0);
+        g.pb_max = m.pieces;
         g.cfg = ctx->knob[KN_X3_BN] == 64 ? 1 : 0;     // 1: 128 x 64 tiles, 256 threads, two workgroups per CU
         // 2: 256 x 64 tiles (fewer bytes per k-tile).  Whole 256-row tiles only: the bias partial rows are laid out
         // per 64 rows, two per 128-row tile, and an even number of those is what both tilings agree on
@@ -746,7 +728,6 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.out_pieces = o.out_pieces; g.out_plane = o.out_plane;
         g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
-        g.ref32 = o.ref32; g.ldref32 = o.ldref32; g.ref16 = o.ref16; g.ldref16 = o.ldref16;
         g.colpart = o.colpart; g.ld_colpart = o.ld_colpart; g.colsign = o.colsign;
         // row tiles fastest: an XCD's run of workgroups then shares ONE column tile, whose weight pieces
         // (the operand loaded straight into registers, one tile ahead) stay in that XCD's L2
@@ -755,28 +736,6 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         HIP_TRY(launch_gemm_pb(EPI_HALFSTEP, g, st));
         return KURBM_OK;
     }
-    g.nseg = pair_codes(ctx, a_pieces, m.pieces, 0u, &g.seg_codes, 0);
-    // tile choice: 128x128 when that already gives every CU two workgroups; the wave-specialised
-    // 128x128 kernel (4 MFMA + 4 loader waves, one workgroup per CU) when there is about one tile per
-    // CU; 128x64 tiles (more, smaller workgroups) for small grids
-    const int tiles128 = ceil_div(rows, 128) * ceil_div(g.N, 128);
-    g.cfg = ctx->knob[KN_BF16_CFG] != KN_AUTO ? ctx->knob[KN_BF16_CFG] : (tiles128 >= 2 * ctx->ncu ? 0 : (2 * tiles128 >= ctx->ncu ? 2 : 1));
-    g.grid_m = ceil_div(rows, 128); g.grid_n = ceil_div(g.N, 128) * (g.cfg == 1 ? 2 : 1);   // covers the 128-padded row
-    g.nkt = g.K / (g.cfg == 1 ? 64 : 128);
-    g.inv_nkt = inv_of(g.nkt);
-    g.kt_total = g.nseg * g.nkt; g.kt_per_split = g.kt_total; g.nsplit = 1;
-    g.bias = vh ? p->b_h : p->b_v;
-    g.act = act; g.noise = noise;
-    if (rng) g.rng = *rng;
-    g.out = o.out; g.ldo = o.ldo; g.ldo_cols = o.out ? o.ldo : g.N;
-    g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
-    g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
-    g.ref32 = o.ref32; g.ldref32 = o.ldref32; g.ref16 = o.ref16; g.ldref16 = o.ldref16;
-    g.colpart = o.colpart; g.ld_colpart = o.ld_colpart;
-    g.m_fastest = (g.grid_m < g.grid_n) ? 1 : 0;
-    if (o.grid_m_out) *o.grid_m_out = g.grid_m;
-    HIP_TRY(launch_gemm_bf16(EPI_HALFSTEP, g, st));
-    return KURBM_OK;
 }
 
 static int mirror_refresh_any(kurbm_ctx* ctx, int pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
@@ -842,8 +801,6 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN)
         return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
     if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1 or 3");
-    if (pieces == 3 && o->mode != KURBM_MODE_VISIBLE_BERNOULLI && ctx->knob[KN_X3_SEGMENTS])
-        return fail(KURBM_ERR_ARG, "KURBM_X3_SEGMENTS covers MODE_VISIBLE_BERNOULLI only");
     if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
     if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
     if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
@@ -865,24 +822,23 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
     // (x3: plus the column sums of v_pos per 64-row band, the positive half of the visible-bias statistics)
-    const bool pb = (pieces == 3) && !ctx->knob[KN_X3_SEGMENTS];
-    const int gp_v = pb ? ceil_div(rows, 64) : 0;
+    const int gp_v = ceil_div(rows, 64);
     // resident planes (kurbm_x3_convert_rows ran once for these rows): no conversion; the positive column sums stay where
     // they are and the slab reducer adds them in front of the negative ones (same order of additions either way)
     const float* part_v_pos = nullptr;
-    if (o->v_planes && pb) {
+    if (o->v_planes) {
         if (!aligned16(o->v_planes)) return fail(KURBM_ERR_ARG, "v_planes is misaligned");
         const VPlanes vp = carve_vplanes(ctx, o->v_planes, rows, p->n_vis, v_pieces);
         w.vb = vp.vb; w.vbT = vp.vbT; part_v_pos = vp.part_v;
     } else if (KURBM_STAGE(0))
         HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Lv, w.Kb, w.vbT, w.Lb, p->n_vis, v_pieces, w.planeV,
-                                   w.planeVT, pb ? w.part_v : nullptr, w.ldv32, st));
+                                   w.planeVT, w.part_v, w.ldv32, st));
     // h_pos ~ p(h | v_pos)                                          rbm.py:120
     RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
     if (KURBM_STAGE(1)) {
         HalfOutB ho;
         ho.out = w.hb; ho.ldo = w.Lh; ho.outT = w.hbT; ho.ldoT = w.Lb;
-        if (pb) { ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.colsign = 1.f; }
+        ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.colsign = 1.f;
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
     }
     const uint16_t* h_cur = w.hb;
@@ -904,14 +860,11 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             if (last) {
                 ho.outT = w.v2bT; ho.ldoT = w.Lb; ho.outT_pieces = vn_pieces; ho.outT_plane = w.planeVT;
                 ho.out_f32 = o->v_chain; ho.ldo32 = ldv;
-                ho.ref32 = v_batch; ho.ldref32 = ldv;
                 ho.grid_m_out = &gm_v;
             }
-            ho.colpart = w.part_v; ho.ld_colpart = w.ldv32;
-            if (pb) {   // -sum(v_neg) below the bands of +sum(v_pos); nothing for the inner steps of CD-k
-                ho.colpart = last ? w.part_v + (size_t)gp_v * w.ldv32 : nullptr;
-                ho.colsign = -1.f;
-            }
+            // -sum(v_neg) below the bands of +sum(v_pos); nothing for the inner steps of CD-k
+            ho.colpart = last ? w.part_v + (size_t)gp_v * w.ldv32 : nullptr; ho.ld_colpart = w.ldv32;
+            ho.colsign = -1.f;
             if ((e = half_step_b(ctx, LAYOUT_HV, p, m, h_cur, w.Lh, 1, 0, rows, act_v, noise_v, &r, ho, st))) return e;
         }
         if (!last && KURBM_STAGE(2)) {
@@ -926,20 +879,19 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     if (KURBM_STAGE(3)) {
         HalfOutB ho;
         ho.outT = w.hnT; ho.ldoT = w.Lb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT;
-        ho.ref16 = w.hb; ho.ldref16 = w.Lh;
-        ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.grid_m_out = &gm_h;
-        if (pb) { ho.colpart = w.part_h + (size_t)2 * ceil_div(rows, 128) * w.ldh32; ho.colsign = -1.f; }
+        ho.colpart = w.part_h + (size_t)2 * ceil_div(rows, 128) * w.ldh32; ho.ld_colpart = w.ldh32; ho.colsign = -1.f;
+        ho.grid_m_out = &gm_h;
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st))) return e;
     }
 
     // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
     // segments: (piece of v_pos) x h_pos, then v_neg x (piece of h_neg), negated
     const int nseg_st = pieces == 3 ? v_pieces + vn_pieces : 2;
-    const OuterPlanB plf = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, nseg_st, pieces == 3);
+    const OuterPlanB plf = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, nseg_st);
     const int Mr = m_hi - m_lo;                         // visible rows of this call (all of them unless only == 7)
     const bool sub = (Mr != p->n_vis);
     // a row range keeps inside the slab memory carved for the whole matrix
-    const OuterPlanB pl = sub ? plan_outer_bf16(ctx, rows, Mr, p->n_hid, nseg_st, pieces == 3,
+    const OuterPlanB pl = sub ? plan_outer_bf16(ctx, rows, Mr, p->n_hid, nseg_st,
                                                 (int)((w.slab_stride * plf.nsplit_bound) / ((size_t)Mr * plf.ld_slab)))
                               : plf;
     const size_t slab_stride = sub ? (size_t)Mr * pl.ld_slab : w.slab_stride;
@@ -953,25 +905,16 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.M = Mr; g.N = p->n_hid; g.K = w.Kb;
         g.grid_m = pl.gm; g.grid_n = pl.gn;
         g.slab = w.slab; g.slab_stride = slab_stride; g.ld_slab = pl.ld_slab;
-        if (pb) {   // (piece of v_pos) x h_pos, then v_neg x (all pieces of h_neg), walked segment-fastest
-            g.nseg = pb_codes(ctx, v_pieces, 1, 0u, &g.seg_codes, 0);
-            g.nseg = pb_codes(ctx, vn_pieces, 3, 1u, &g.seg_codes, g.nseg);
-            g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
-            g.m_fastest = ctx->knob[KN_X3_STATS_MFAST];
-            g.cfg = ctx->knob[KN_X3_BN] == 64 ? 1 : 0;
-            g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
-            g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
-            HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
-        } else {
-            g.nseg = pair_codes(ctx, v_pieces, 1, 0u, &g.seg_codes, 0);
-            g.nseg = pair_codes(ctx, 1, pieces, 1u, &g.seg_codes, g.nseg);
-            g.nkt = w.Kb / 128; g.inv_nkt = inv_of(g.nkt);
-            g.kt_total = g.nseg * g.nkt;
-            g.nsplit = pl.nsplit; g.kt_per_split = ceil_div(g.kt_total, g.nsplit);
-            g.nsplit = ceil_div(g.kt_total, g.kt_per_split);
-            nslab_used = g.nsplit;
-            HIP_TRY(launch_gemm_bf16(EPI_SLAB, g, st));
-        }
+        // (piece of v_pos) x h_pos, then v_neg x (all pieces of h_neg), walked segment-fastest
+        g.nseg = pb_codes(ctx, v_pieces, 1, 0u, &g.seg_codes, 0);
+        g.nseg = pb_codes(ctx, vn_pieces, pieces, 1u, &g.seg_codes, g.nseg);
+        g.pb_max = pieces;
+        g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
+        g.m_fastest = ctx->knob[KN_X3_STATS_MFAST];
+        g.cfg = ctx->knob[KN_X3_BN] == 64 ? 1 : 0;
+        g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
+        g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
+        HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
     }
     ReduceArgs a;
     memset(&a, 0, sizeof a);
@@ -983,10 +926,10 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     const bool ap = o->apply != 0;
     a.W = (ap && (which & 1)) ? p->W : nullptr;
     a.delta_w = o->delta_out ? o->delta_out + (size_t)m_lo * p->n_hid : nullptr;
-    a.part_h = w.part_h; a.nrow_tiles_h = pb ? 4 * gm_h : gm_h; a.ld_part_h = w.ldh32;
+    a.part_h = w.part_h; a.nrow_tiles_h = 4 * gm_h; a.ld_part_h = w.ldh32;
     a.b_h = (ap && (which & 2)) ? p->b_h : nullptr;
     a.delta_bh = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid : nullptr;
-    a.part_v = w.part_v; a.nrow_tiles_v = pb ? gp_v + 2 * gm_v : gm_v; a.ld_part_v = w.ldv32;
+    a.part_v = w.part_v; a.nrow_tiles_v = gp_v + 2 * gm_v; a.ld_part_v = w.ldv32;
     if (part_v_pos) {   // rows [0, gp_v) from the resident planes, then the workspace's negative rows
         a.part_v = part_v_pos; a.nrow_tiles_v = gp_v;
         a.part_v2 = w.part_v + (size_t)gp_v * w.ldv32; a.nrow_tiles_v2 = 2 * gm_v;

@@ -110,11 +110,11 @@ struct FinishArgs {
     int rows, n_vis, ldv, ncol_tiles, ld_rowpart;
 };
 
-// bf16 NT GEMM (kurbm_bf16.hip): A [M][lda], B [N][ldb] bf16, k contiguous and zero-padded to 128.
+// bf16 NT GEMM (k_gemm_pb, kurbm_x3.hip): A [M][lda], B [N][ldb] bf16, k contiguous and zero-padded to 128.
 // The k range is a list of up to MAX_SEG SEGMENTS of K elements each.  Segment s multiplies piece ia of
-// operand set `neg` of A with piece ib of the same set of B (pieces = the bf16 hi / mid / lo parts of an
-// fp32 plane, `*_plane` elements apart); set 1 enters negated (the negative phase of the statistics).
-// seg_codes packs one 5-bit code per segment: bits 0-1 ia, bits 2-3 ib, bit 4 set.
+// operand set `neg` of A with pieces 0 .. npb-1 of the same set of B (pieces = the bf16 hi / mid / lo parts of an
+// fp32 plane, `*_plane` elements apart; one piece on the rounded-bf16 path); set 1 enters negated (the negative phase
+// of the statistics).  seg_codes packs one 5-bit code per segment: bits 0-1 ia, bits 2-3 npb, bit 4 set.
 constexpr int MAX_SEG = 12;
 struct GemmArgsB {
     const uint16_t* A0;
@@ -130,6 +130,7 @@ struct GemmArgsB {
     int seg_fastest;
     uint32_t inv_nseg;
     int side;             // k_gemm_pb: some test plane (prob_f32 / out_u) is requested
+    int pb_max;           // k_gemm_pb: most B pieces any segment multiplies (3: x3; 1: the rounded-bf16 path)
     // filled by launch_gemm_pb: one buffer descriptor per operand (base = the lower of the two sets'
     // pointers) and each set's byte offset from it, so that a tile is a scalar offset, never a pointer
     const uint16_t* baseA;
@@ -140,8 +141,7 @@ struct GemmArgsB {
     int nseg, nkt, kt_total, kt_per_split, nsplit;
     int grid_m, grid_n;
     int m_fastest;
-    int cfg;              // 0: 128x128 tile, k-tile 128 (one workgroup per CU); 1: 128x64, k-tile 64 (two per CU);
-                          // 2: 128x128 / 128 wave-specialised (512 threads: 4 MFMA waves + 4 loader waves)
+    int cfg;              // 0: 128 x 128 tile; 1: 128 x 64 (two workgroups per CU); 2: 256 x 64 (half steps)
     // half-step epilogue
     const float* bias;
     int act, noise;
@@ -159,10 +159,6 @@ struct GemmArgsB {
     float* prob_f32;      // fp32 probabilities next to a sampled plane (tests); nullable
     float* out_u;         // fp32 uniforms (tests); nullable
     int ldo32;
-    const float* ref32;   // column partials of (ref - value): fp32 reference ...
-    int ldref32;
-    const uint16_t* ref16;  // ... or bf16 reference
-    int ldref16;
     float* colpart;
     int ld_colpart;
     float colsign;        // k_gemm_pb: colpart[bm][col] = colsign * (column sum of the value plane over the tile's rows)
@@ -183,7 +179,6 @@ struct GemmArgsB {
 
 unsigned long long* get_stamp_buffer();
 void tile_shape(int cfg, int* bm, int* bn);
-hipError_t launch_gemm_bf16(int epi, const GemmArgsB& g, hipStream_t st);
 hipError_t launch_gemm_pb(int epi, const GemmArgsB& g, hipStream_t st);
 // pieces = 1: round to nearest bf16; 3: exact split x = hi + mid + lo, piece j at out + j * out_plane
 // colpart (nullable): [ceil(rows / 64)][ld_colpart] column sums of each 64-row band of `in`

@@ -67,7 +67,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // ds_write path) then never sits in the instruction stream of a wave that has MFMAs to issue: with staging in the MFMA
 // waves the k loop took twice the time of its MFMAs alone (ablation build), wherever in the tile the staging was put.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int PB, int EPI, int NOISE, bool WS = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2) void k_gemm_pb(GemmArgsB g) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 * WAVES_M * WAVES_N + 256) / 256 : 2) void k_gemm_pb(GemmArgsB g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;          // threads of the MFMA waves (and of every epilogue loop)
     constexpr int NTS = WS ? 256 : NT;                  // threads that stage tiles
     // LDS rows are the bare 128-byte k-tile, their eight 16-byte chunks XOR-swizzled with (row >> 1) & 7.
@@ -637,7 +637,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
             cs += __shfl_xor(cs, 16);
             cs += __shfl_xor(cs, 32);
             const int col = colb + ni * 16;
-            if (slot == 0 && col < g.N) g.colpart[(size_t)(bm * WAVES_M + wm) * g.ld_colpart + col] = g.colsign * cs;
+            // (the host lays colpart out as one row per 64 rows of the tile: a wave that covers more writes its sum to the
+            //  first of its rows and zeros to the others)
+            constexpr int RPW = WM / 64;
+            static_assert(WM % 64 == 0, "column partials: one row per 64 tile rows");
+            if (slot == 0 && col < g.N) {
+                float* cp = g.colpart + (size_t)((bm * WAVES_M + wm) * RPW) * g.ld_colpart + col;
+                cp[0] = g.colsign * cs;
+#pragma unroll
+                for (int q = 1; q < RPW; ++q) cp[(size_t)q * g.ld_colpart] = 0.f;
+            }
         }
     }
 
@@ -743,8 +752,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? 3 : 2
 }
 
 // ------------------------------------------------------------------------------------
-// launcher: 128 x 128 tiles, 512 threads
+// launcher
 // ------------------------------------------------------------------------------------
+// one (pieces, epilogue, noise) combination: tile configuration by g.cfg (0: 128 x 128, 1: 128 x 64 two workgroups per CU,
+// 2: 256 x 64 half steps); only the combinations the host plans are instantiated
+template <int PBN, int E, int NZ>
+static hipError_t launch_pb(const GemmArgsB& g, int nblk, int ws, hipStream_t st) {
+    if (g.cfg == 2) {
+        if constexpr (E == EPI_HALFSTEP) hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+        else return hipErrorInvalidValue;
+    } else if (g.cfg == 1) {
+        if constexpr (PBN == 3) hipLaunchKernelGGL((k_gemm_pb<128, 64, 2, 2, 64, PBN, E, NZ>), dim3(nblk), dim3(256), 0, st, g);
+        else return hipErrorInvalidValue;
+    } else if (ws || PBN == 1) {
+        hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+    } else {
+        if constexpr (PBN == 3) hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ>), dim3(nblk), dim3(512), 0, st, g);
+        else return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     GemmArgsB g = g_in;
     {   // diagnostic build: launch n after the buffer was set writes at base + n * 4096 entries
@@ -785,30 +813,23 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     }
     static const int ws = getenv("KURBM_X3_WS") ? atoi(getenv("KURBM_X3_WS")) : 1;
     // cfg 2: 256 x 64 tiles for the half steps (A tile 32 KB + three 8-KB pieces of B = 56 KB per k-tile instead of 64 KB
-    // for the same MFMAs: the k loop moves with the bytes a CU takes in)
-#define KURBM_PB_TALL(NZ)                                                                            \
-    if (epi == EPI_HALFSTEP && g.cfg == 2 && g.noise == NZ) {                                        \
-        hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, 3, EPI_HALFSTEP, NZ, true>), dim3(nblk), dim3(768), 0, st, g); \
-        return hipGetLastError();                                                                    \
+    // for the same MFMAs: the k loop moves with the bytes a CU takes in).  pb_max = 1: every segment has ONE piece of B (the
+    // rounded-bf16 path, kurbm_cd_step_bf16): the same kernel with a k-tile of A + one B tile.
+#define KURBM_PB_ANY(PBN, E, NZ) \
+    if (epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) return launch_pb<PBN, E, NZ>(g, nblk, ws, st);
+    if (g.pb_max == 1) {
+        KURBM_PB_ANY(1, EPI_HALFSTEP, NOISE_NONE)
+        KURBM_PB_ANY(1, EPI_HALFSTEP, NOISE_BERNOULLI)
+        KURBM_PB_ANY(1, EPI_HALFSTEP, NOISE_GAUSSIAN)
+        KURBM_PB_ANY(1, EPI_SLAB, NOISE_NONE)
+        return hipErrorInvalidValue;
     }
-    KURBM_PB_TALL(NOISE_NONE)
-    KURBM_PB_TALL(NOISE_BERNOULLI)
-    KURBM_PB_TALL(NOISE_GAUSSIAN)
-#undef KURBM_PB_TALL
-    if (g.cfg == 2) return hipErrorInvalidValue;
-#define KURBM_PB(E, NZ)                                                                              \
-    if (epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) {                                          \
-        if (g.cfg == 1) hipLaunchKernelGGL((k_gemm_pb<128, 64, 2, 2, 64, 3, E, NZ>), dim3(nblk), dim3(256), 0, st, g); \
-        else if (ws) hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, 3, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g); \
-        else hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, 3, E, NZ>), dim3(nblk), dim3(512), 0, st, g); \
-        return hipGetLastError();                                                                    \
-    }
-    KURBM_PB(EPI_HALFSTEP, NOISE_NONE)
-    KURBM_PB(EPI_HALFSTEP, NOISE_BERNOULLI)
-    KURBM_PB(EPI_HALFSTEP, NOISE_GAUSSIAN)
-    KURBM_PB(EPI_SLAB, NOISE_NONE)
-    KURBM_PB(EPI_SOFTPLUS, NOISE_NONE)
-#undef KURBM_PB
+    KURBM_PB_ANY(3, EPI_HALFSTEP, NOISE_NONE)
+    KURBM_PB_ANY(3, EPI_HALFSTEP, NOISE_BERNOULLI)
+    KURBM_PB_ANY(3, EPI_HALFSTEP, NOISE_GAUSSIAN)
+    KURBM_PB_ANY(3, EPI_SLAB, NOISE_NONE)
+    KURBM_PB_ANY(3, EPI_SOFTPLUS, NOISE_NONE)
+#undef KURBM_PB_ANY
     return hipErrorInvalidValue;
 }
 

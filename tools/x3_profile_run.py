@@ -16,6 +16,8 @@ dev = torch.device("cuda", 0)
 g = np.random.default_rng(1)
 eng = DeviceRBM(g.uniform(-0.05, 0.05, (NV, NH)).astype(np.float32), np.zeros(NH, np.float32), np.zeros(NV, np.float32), dev)
 V = DeviceMatrix.from_host((g.random((B, NV)) < 0.19).astype(np.float32), dev)
+# as RBM.fit does on the x3 path: the bf16 planes of the batch are made once, the steps read them
+planes = eng.make_planes(V, [(0, B)]) if compute == "x3" and os.environ.get("PROFILE_NO_PLANES", "0") != "1" else None
 for i in range(60):
-    eng.cd_step(V, B, 0, 1e-3 / B, 42, i, compute=compute)
+    eng.cd_step(V, B, 0, 1e-3 / B, 42, i, compute=compute, planes=planes)
 torch.cuda.synchronize()
