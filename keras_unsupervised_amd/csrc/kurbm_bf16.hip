@@ -2,8 +2,7 @@
 // conversion (rounded, or the exact three-piece split), the slab reduction that also rewrites the weight-piece mirror, the
 // bf16-exactness check.  The GEMM itself is k_gemm_pb (kurbm_x3.hip) for both paths: PB = 3 pieces per weight for x3,
 // PB = 1 for the rounded-bf16 path of BASELINE.json config 5 (its first kernel, k_gemm_bf16, measured the same 1.20 ms per
-// 4096 x 4096 PCD-10 step as k_gemm_pb<PB = 1> and was removed: a 128 x 128 bf16 tile is bound by the ~50 GB/s a CU pulls
-// from L2 with two tiles in flight, whatever the staging looks like -- DESIGN.md section 4).
+// 4096 x 4096 PCD-10 step as k_gemm_pb<PB = 1> and was removed -- DESIGN.md section 4).
 //
 // bf16 operands run 16x faster on the matrix cores (v_mfma_f32_16x16x32_bf16) than fp32 ones, provided every GEMM
 // operand is k-contiguous.  So these paths keep bf16 MIRRORS in both orientations instead of re-staging:

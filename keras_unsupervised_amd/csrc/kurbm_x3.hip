@@ -24,11 +24,13 @@
 // rows of its column); only the row-major bf16 plane takes a trip through LDS (bf16 patch of the whole
 // tile, then 16-byte coalesced rows).
 //
-// Measured (MI355X, config 2): a half step is 29-31 us (prologue 4, k loop 18 at ~1.3 PFLOP/s,
-// draw + sigmoid 2, plane stores 4), the statistics GEMM 38 us; 645-685 executed bf16 TFLOP/s per launch.  L2 hit
-// rate 75 %: every XCD pulls all weight pieces.  Tried and dropped (git history): pieces loaded straight into
-// registers without LDS (15 % slower), padded leading dimensions, staggered k walks, row-tile-fastest block order
-// (all equal), Philox calls spread over the k loop through wave-uniform selects (scratch).
+// Measured (MI355X, config 2, round 2; DESIGN.md section 4, profiles/r02_b_*): half steps 27-28 us on 256 x 64 tiles (about
+// 4 us until the first tile has landed, 17 us of k loop, 2-3 us draw + sigmoid, 3-4 us of plane stores), the statistics GEMM
+// 36 us; 700-750 executed bf16 TFLOP/s per launch, MFMA busy 36-42 %, L2 hit rate 81 % with the XCD 2-D blocks.  Tried and
+// dropped (git history): pieces loaded straight into registers without LDS (15 % slower), padded leading
+// dimensions, staggered k walks, row-tile-fastest block order (all equal), Philox calls spread over the k loop through
+// wave-uniform selects (scratch), four MFMA waves of 128 x 32 outputs (25-75 % slower), 0/1 planes as bytes (timing-only
+// build KURBM_ABLATE=4: 2-6 %, not worth the rewrite).
 //
 // Reference op sequences: ku/ebm/rbm.py:46-47 (v->h), :52-53 / :121-123 (h->v), :124 (h_neg), :125-134
 // (statistics); the split is an implementation choice of this build.
@@ -219,13 +221,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
         return;   // timing-only build: no global loads (the registers keep whatever they hold)
 #endif
         if (part == 0) {
+#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 4)
+            constexpr int NAL = NA / 2;   // timing-only build: an A tile of bytes is half the chunks
+#else
+            constexpr int NAL = NA;
+#endif
             if (r.neg) {   // (wave-uniform)
 #pragma unroll
-                for (int it = 0; it < NA; ++it)
+                for (int it = 0; it < NAL; ++it)
                     R.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA1, goffA[it], r.oa, 0));
             } else {
 #pragma unroll
-                for (int it = 0; it < NA; ++it)
+                for (int it = 0; it < NAL; ++it)
                     R.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA0, goffA[it], r.oa, 0));
             }
         } else {
@@ -259,6 +266,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
         for (int c = 0; c < NCH; ++c) {
             if (c < c0 || c >= c1) continue;
             if (c < NA) {
+#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 4)
+                if (c >= NA / 2) continue;
+#endif
                 u32x4 v = R.a[c];
                 if (SIGNED) { v.x ^= r.flip; v.y ^= r.flip; v.z ^= r.flip; v.w ^= r.flip; }
                 *reinterpret_cast<u32x4*>(a + soffA[c]) = v;
@@ -280,6 +290,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
     const int swz = (l15 >> 1) & 7;
     auto frag_a = [&](int buf, int ks, u32x4 (&f)[TM]) __attribute__((always_inline)) {
         const unsigned char* c = smem + buf * STAGE + (wm * WM + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
+#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 4)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {   // timing-only: 8 bytes per fragment, expanded by four v_perm_b32
+            const u32x2 raw = *reinterpret_cast<const u32x2*>(c + mi * 16 * ROWB);
+            f[mi] = u32x4{__builtin_amdgcn_perm(0u, raw.x, 0x010C000Cu), __builtin_amdgcn_perm(0u, raw.x, 0x030C020Cu),
+                          __builtin_amdgcn_perm(0u, raw.y, 0x010C000Cu), __builtin_amdgcn_perm(0u, raw.y, 0x030C020Cu)};
+        }
+        return;
+#endif
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
     };

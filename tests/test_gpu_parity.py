@@ -347,6 +347,35 @@ def test_rbm_transform_surface(gpu_device):
     assert cfg["output_dim"] == nh and cfg["mode"] == MODE_VISIBLE_BERNOULLI
 
 
+def test_rbm_call_input_kinds(gpu_device):
+    """call / transform / cal_free_energy take numpy arrays, torch tensors (host or device) and DeviceMatrix objects, and
+    answer in kind: ndarray -> ndarray, tensor -> tensor ON THE INPUT'S DEVICE, DeviceMatrix -> DeviceMatrix."""
+    from keras_unsupervised_amd.ebm import MODE_VISIBLE_BERNOULLI, RBM
+    from keras_unsupervised_amd.ebm.engine import DeviceMatrix
+    nv, nh = 40, 24
+    W, b_h, b_v = synthetic_params(nv, nh, seed=3)
+    V = synthetic_binary(10, nv, seed=4)
+
+    def fresh():
+        return RBM({"batch_size": 4, "epochs": 1, "lr": 0.1}, nh, mode=MODE_VISIBLE_BERNOULLI, seed=11, weights=(W, b_h, b_v))
+
+    ref = O.transform(W, b_h, V, 11, 0)
+    out = fresh()(V)
+    assert isinstance(out, np.ndarray) and np.array_equal(out, ref)
+    out = fresh()(torch.from_numpy(V))                                   # host tensor in, host tensor out
+    assert isinstance(out, torch.Tensor) and out.device.type == "cpu" and np.array_equal(out.numpy(), ref)
+    out = fresh()(torch.from_numpy(V).to(gpu_device))
+    assert out.device == gpu_device and np.array_equal(out.cpu().numpy(), ref)
+    out = fresh()(DeviceMatrix.from_host(V, gpu_device))                 # a DeviceMatrix has no .shape: used to raise
+    assert isinstance(out, DeviceMatrix) and np.array_equal(out.to_numpy(), ref)
+    r = fresh()
+    F = r.cal_free_energy(torch.from_numpy(V))
+    assert isinstance(F, list) and F[0].device.type == "cpu"
+    assert rel_err(F[0].numpy(), O.free_energy(V, W, b_h, b_v)) <= TOL
+    H = r.transform(torch.from_numpy(V))
+    assert isinstance(H, list) and H[0].device.type == "cpu"
+
+
 def test_dbn_golden(gpu_device, golden_dir, capsys):
     from keras_unsupervised_amd.ebm import DBN, MODE_VISIBLE_BERNOULLI, RBM
     g = np.load(os.path.join(golden_dir, "dbn_small.npz"))
@@ -950,6 +979,29 @@ def test_x3_gaussian_visibles_vs_oracle(gpu_device, cfg):
     out = e.half_step_bf16("hv", _dm(h, gpu_device), B, 2, 2, 3, 1, 1, pieces=3)
     loc, z, v1 = O.sample_visible(h, W, b_v, O.Rng(3, 1), 1, mode)
     assert np.max(np.abs(out["prob"].to_numpy() - loc)) <= TOL and np.max(np.abs(out["sample"].to_numpy() - v1)) <= TOL
+
+
+def test_x3_gaussian_persistent_chain_is_not_rounded(gpu_device):
+    """Gaussian mode with persistent chains on 0/1 DATA: the data is one bf16 piece, but the chain holds real-valued
+    N(loc, 1) draws after the first step and must travel as three pieces.  (A cached "this buffer is bf16-exact" from
+    the chain's initial contents would round the fantasy particles to 8 bits: the second step's sums would then be off
+    by ~1e-2, not 1e-5.)"""
+    B, nv, nh = 256, 200, 136
+    mode = O.MODE_VISIBLE_GAUSSIAN
+    W, b_h, b_v = synthetic_params(nv, nh, seed=2100)
+    v = synthetic_binary(B, nv, seed=2101, p=0.3)
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd, cd = _dm(v, gpu_device), _dm(v, gpu_device)              # chain starts as a copy of the (bf16-exact) data
+    assert e.v_pieces(vd) == 1
+    e.cd_step(vd, B, 0, 1e-3, 7, 0, mode=mode, v_chain=cd, apply=False, emit_delta=True, compute="x3")
+    chain1 = cd.to_numpy().copy()
+    assert not np.array_equal(chain1, O.bf16_round(chain1))      # real-valued now
+    d2 = _gpu_cd_delta(e, vd, B, 1e-3, 7, 1, mode=mode, v_chain=cd, compute="x3")
+    _, _, _, ch, _ = O.cd_step_fused(W, b_h, b_v, v, 1e-3, 7, 1, mode=mode, v_chain=chain1)
+    dW_ref, dbh_ref, dbv_ref = O.cd_statistics({k_: ch[k_].astype(np.float64) for k_ in ("v_pos", "h_pos", "v_neg", "h_neg")})
+    dW, dbh, dbv = _split(d2, nv, nh)
+    assert rel_err(dW, dW_ref) <= TOL and rel_err(dbh, dbh_ref) <= TOL and rel_err(dbv, dbv_ref) <= TOL
+    assert np.max(np.abs(cd.to_numpy() - ch["v_neg"])) <= TOL
 
 
 @pytest.mark.parametrize("shape", [(6, 64, 48), (150, 300, 200), (1024, 784, 1024), (1100, 130, 257)])
