@@ -29,6 +29,27 @@ def test_library_exports_every_declared_symbol():
     assert lib.kurbm_abi_version() == 2
 
 
+def test_header_is_plain_c_and_structs_match(tmp_path):
+    """include/kurbm.h compiles as C99 with gcc (no C++, no HIP, no torch types in the boundary), and the struct layouts
+    the ctypes table assumes are the ones the C compiler produces."""
+    import ctypes as C
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "kurbm.h"\n'
+        'int main(void) {\n'
+        '  printf("%zu %zu %zu %zu %zu %zu %d %d\\n", sizeof(kurbm_params), offsetof(kurbm_params, W), sizeof(kurbm_rng),\n'
+        '         sizeof(kurbm_cd_opts), offsetof(kurbm_cd_opts, v_planes), offsetof(kurbm_cd_opts, seed),\n'
+        '         KURBM_ABI_VERSION, KURBM_UNIQUE_ID_BYTES);\n'
+        '  return 0; }\n')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(x) for x in out] == [C.sizeof(_lib.Params), _lib.Params.W.offset, C.sizeof(_lib.Rng), C.sizeof(_lib.CdOpts),
+                                     _lib.CdOpts.v_planes.offset, _lib.CdOpts.seed.offset, _lib.ABI_VERSION, _lib.UNIQUE_ID_BYTES]
+
+
 def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(_lib.Params) == 40 and _lib.Params.W.offset == 16

@@ -806,6 +806,19 @@ def test_comm_through_c_abi(gpu_device, one_rank_comm):
     from keras_unsupervised_amd import _lib
     with pytest.raises(_lib.KurbmError):                       # a null communicator is an error code, not a fault
         _lib.check(comm.lib.kurbm_allreduce_sum_f32(None, y.data_ptr(), 4, None))
+    # one process driving its GPUs (ncclCommInitAll): the array form, here with the one device of this box
+    import ctypes as C
+    devs = (C.c_int * 1)(gpu_device.index)
+    out = (C.c_void_p * 1)()
+    _lib.check(comm.lib.kurbm_comm_init_all(1, devs, out))
+    assert comm.lib.kurbm_comm_count(out[0]) == 1 and comm.lib.kurbm_comm_rank(out[0]) == 0
+    st = C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+    _lib.check(comm.lib.kurbm_allreduce_sum_f32(out[0], y.data_ptr(), y.numel(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    comm.lib.kurbm_comm_destroy(out[0])
+    with pytest.raises(_lib.KurbmError, match="rank 3 of 2"):   # bad rank: refused before RCCL is asked
+        _lib.check(comm.lib.kurbm_comm_init_rank(gpu_device.index, 2, 3, C.create_string_buffer(128), 128, C.byref(C.c_void_p())))
 
 
 @pytest.mark.parametrize("cfg", [dict(B=300, nv=784, nh=256, k=1), dict(B=260, nv=1100, nh=200, k=2, pcd=True),
