@@ -403,6 +403,21 @@ def test_dbn_golden(gpu_device, golden_dir, capsys):
         DBN().fit(Vd)                                                           # dbn.py:47-48
 
 
+def test_c_abi_from_plain_c(gpu_device, tmp_path):
+    """The boundary is a C ABI: examples/c/cd_step_demo.c (C99, gcc, HIP runtime API for memory, no Python or PyTorch in the
+    process) runs one CD-1 update on the fp32-MFMA and on the x3 entry points with resident planes and compares them."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "keras_unsupervised_amd", "csrc")
+    exe = str(tmp_path / "cd_step_demo")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(root, "examples", "c", "cd_step_demo.c"), "-L", csrc, "-lkurbm", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    "-lm", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi 2" in r.stdout
+
+
 def test_c_abi_error_behaviour(gpu_device):
     """Bad arguments come back as error codes with a message, never as a fault."""
     from keras_unsupervised_amd import _lib
