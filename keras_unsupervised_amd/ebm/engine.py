@@ -87,7 +87,7 @@ class DeviceMatrix:
         return self.t.data_ptr() + row * self.ld * 4
 
     def to_numpy(self):
-        return self.t[: self.rows, : self.cols].contiguous().cpu().numpy()
+        return self.t[: self.rows, : self.cols].contiguous().cpu().numpy()      # (rows may be 0: an empty [0, cols] array)
 
     def view(self):
         """[rows, cols] torch view (device)."""

@@ -165,6 +165,11 @@ class RBM(object):
         return [out] if as_list else out
 
     def _half(self, direction, x, act, noise, stream_id):
+        if x.rows == 0:
+            # an empty batch yields an empty result (K.function on a [0, n] feed does); the call still counts for the RNG
+            self._call_count += 1
+            n_out = self._dev.n_hid if direction == "vh" else self._dev.n_vis
+            return DeviceMatrix.zeros(0, n_out, self._dev.device)
         # large inputs (a whole data set between DBN layers) go through the x3 kernels too
         if self._large(x.rows):
             out = self._dev.half_step_bf16(direction, x, x.rows, act, noise, self.seed, stream_id, self._call_count, pieces=3,
@@ -211,7 +216,10 @@ class RBM(object):
         """F(v) = -(v.b_v + sum_j softplus((v.W + b_h)_j))   (free_energy_func, rbm.py:97-98 -> :73-76)."""
         self._ensure_built(self._n_cols(v))
         x, kind = self._as_device(v)
-        F = self._dev.free_energy(x, x.rows, compute="x3" if self._large(x.rows) else None)
+        if x.rows == 0:
+            F = torch.empty(0, dtype=torch.float32, device=self._dev.device)
+        else:
+            F = self._dev.free_energy(x, x.rows, compute="x3" if self._large(x.rows) else None)
         if kind == "device":
             return F
         if isinstance(kind, torch.device):          # torch input: the result goes back to the input's device

@@ -376,6 +376,35 @@ def test_rbm_call_input_kinds(gpu_device):
     assert isinstance(H, list) and H[0].device.type == "cpu"
 
 
+def test_empty_inputs(gpu_device):
+    """Empty feeds: transform / inv_transform / cal_free_energy of a [0, n] array give [0, m] / [0] results, fit of an
+    empty matrix takes no step (rbm.py:110-111: num_step = 0), a DBN passes the empty matrix through its layers."""
+    from keras_unsupervised_amd.ebm import DBN, MODE_VISIBLE_BERNOULLI, RBM
+    nv, nh = 40, 24
+    W0 = synthetic_params(nv, nh, seed=3)
+    r = RBM({"batch_size": 4, "epochs": 2, "lr": 0.1}, nh, mode=MODE_VISIBLE_BERNOULLI, seed=11, weights=W0)
+    empty = np.zeros((0, nv), np.float32)
+    H = r.transform(empty)
+    assert H[0].shape == (0, nh)
+    assert r.inv_transform(np.zeros((0, nh), np.float32))[0].shape == (0, nv)
+    assert r.cal_free_energy(empty)[0].shape == (0,)
+    assert r.fit(empty, verbose=1) is None and r._update_count == 0
+    for x, y in zip(r.get_weights(), W0):
+        assert np.array_equal(x, y)
+    r3 = RBM({"batch_size": 1024, "epochs": 1, "lr": 0.1}, nh, mode=MODE_VISIBLE_BERNOULLI, seed=11, weights=W0)     # x3 path
+    assert r3.fit(empty, verbose=0) is None and r3._update_count == 0
+    d = DBN()
+    d.add_stack(r)
+    d.add_stack(RBM({"batch_size": 4, "epochs": 1, "lr": 0.1}, 8, mode=MODE_VISIBLE_BERNOULLI, seed=2, weights=synthetic_params(nh, 8, seed=4)))
+    assert d.transform(empty).shape == (0, 8)
+    # a single row and a batch size larger than the data set
+    one = synthetic_binary(1, nv, seed=5)
+    r1 = RBM({"batch_size": 64, "epochs": 1, "lr": 0.01}, nh, mode=MODE_VISIBLE_BERNOULLI, seed=11, weights=W0)
+    r1.fit(one, verbose=0)
+    Wr, bhr, bvr, _, _ = O.cd_step_fused(*W0, one, 0.01, 11, 0)
+    assert np.max(np.abs(r1.rbm_weight - Wr)) <= TOL and np.max(np.abs(r1.visible_bias - bvr)) <= TOL
+
+
 def test_dbn_golden(gpu_device, golden_dir, capsys):
     from keras_unsupervised_amd.ebm import DBN, MODE_VISIBLE_BERNOULLI, RBM
     g = np.load(os.path.join(golden_dir, "dbn_small.npz"))
