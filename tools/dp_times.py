@@ -72,3 +72,28 @@ for name, s2 in (("normal-priority side stream", torch.cuda.Stream(dev)), ("high
         main.wait_event(e2)
 
     print("hop main -> %s -> main" % name, t(hop))
+
+# the same with a NON-NULL main stream (torch's default stream is the legacy null stream)
+comm = dp.Comm(dev, 0, 1, dp.Comm.new_unique_id())
+own = torch.cuda.Stream(dev)
+with torch.cuda.stream(own):
+    print("--- launches on an own (non-null) stream")
+    print("local x3 step              ", t(lambda: eng.cd_step(V, B, 0, lr, 42, 0, compute="x3")))
+    for n in (1, 2, 3):
+        print("kurbm_cd_step_x3_dp, %d range" % n, t(lambda n=n: eng.cd_step_dp(comm, V, B, 0, lr, 42, 0, compute="x3", n_chunks=n)))
+    s2 = torch.cuda.Stream(dev)
+    x = torch.zeros(1 << 20, device=dev)
+
+    def hop2():
+        x.add_(1.0)
+        e = torch.cuda.Event()
+        e.record(own)
+        s2.wait_event(e)
+        with torch.cuda.stream(s2):
+            x.add_(1.0)
+        e2 = torch.cuda.Event()
+        e2.record(s2)
+        own.wait_event(e2)
+
+    print("hop own -> side -> own     ", t(hop2))
+comm.destroy()
