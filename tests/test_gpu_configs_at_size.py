@@ -126,6 +126,49 @@ def test_config2_x3_stagewise(gpu_device):
 
 
 @pytest.mark.parametrize("compute", ["x3", "fp32"])
+def test_config2_gaussian_default_mode_stagewise(gpu_device, compute):
+    """configs[1]'s shape in the reference's DEFAULT mode (MODE_VISIBLE_GAUSSIAN, rbm.py:22) on grey-level data: relu-threshold
+    hidden draws (rbm.py:58-59), v_neg ~ N(h.W^T + b_v, 1) (rbm.py:64-66), sigmoid h_neg (rbm.py:145), each stage teacher-forced
+    on the GPU's previous one and held to 1e-4; then the fused step's sums against float64 statistics of those states."""
+    from oracle.make_golden import synthetic_real
+    B, nv, nh = 4096, 784, 1024
+    mode = O.MODE_VISIBLE_GAUSSIAN
+    W, b_h, b_v = synthetic_params(nv, nh, seed=1)
+    W = (W * np.float32(4.0)).astype(np.float32)          # pre-activations that cross the relu threshold's (0, 1) range
+    v = (np.floor(synthetic_real(B, nv, seed=77) * 256.0) / 255.0).astype(np.float32)      # grey levels k / 255
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(v, gpu_device)
+    seed, step, lr = 42, 3, 1e-3 / B
+    rng = O.Rng(seed, step)
+
+    def hook(direction, x, act, noise, stream):
+        if compute == "fp32":
+            return e.half_step(direction, x, B, 0, act, noise, seed, stream, step, want_sample=bool(noise), want_prob=True, want_u=(noise == 1))
+        return e.half_step_bf16(direction, x, B, act, noise, seed, stream, step, pieces=3)
+
+    o = hook("vh", vd, 1, 1, O.stream_h(0))                                              # relu threshold, Bernoulli draw
+    flips = check_half_step(o, *O.sample_hidden(v, W, b_h, rng, O.stream_h(0), mode))
+    h_pos = o["sample"].to_numpy()
+    o2 = hook("hv", o["sample"], 2, 2, O.stream_v(1))                                    # linear mean + N(0, 1)
+    loc, z, v1 = O.sample_visible(h_pos, W, b_v, rng, O.stream_v(1), mode)
+    assert np.max(np.abs(o2["prob"].to_numpy() - loc)) <= TOL and np.max(np.abs(o2["sample"].to_numpy() - v1)) <= TOL
+    v_neg = o2["sample"].to_numpy()
+    o3 = hook("vh", o2["sample"], 0, 0, 0)                                               # sigmoid in both modes (rbm.py:145)
+    h_neg = o3["prob"].to_numpy()
+    assert np.max(np.abs(h_neg - O.sigmoid(v_neg @ W + b_h))) <= TOL
+    assert flips < 64
+    e.cd_step(vd, B, 0, lr, seed, step, mode=mode, apply=False, emit_delta=True, compute=compute)
+    torch.cuda.synchronize()
+    dW, dbh, dbv = _split(e.delta_buffer().cpu().numpy().copy(), nv, nh)
+    v64, vn64, hp64, hn64 = (a.astype(np.float64) for a in (v, v_neg, h_pos, h_neg))
+    ref = v64.T @ hp64 - vn64.T @ hn64
+    scale = np.abs(v64).T @ hp64 + np.abs(vn64).T @ hn64 + 1.0                          # the un-cancelled magnitude
+    assert np.max(np.abs(dW - ref) / scale) <= 2 * STAT_TOL
+    assert np.max(np.abs(lr * dW - lr * ref)) <= TOL
+    assert rel_err(dbv, v64.sum(0) - vn64.sum(0)) <= TOL and rel_err(dbh, hp64.sum(0) - hn64.sum(0)) <= TOL
+
+
+@pytest.mark.parametrize("compute", ["x3", "fp32"])
 def test_config3_eight_shards_of_32768_rows(gpu_device, compute):
     """configs[2]: one 32 768-row batch as eight 4096-row shards, shard r with row0 = r * 4096 (global-row Philox
     counters), each on its own replica ("rank"); the packed sums added up are what the sum all-reduce leaves.  Checked
