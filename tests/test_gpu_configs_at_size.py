@@ -242,6 +242,32 @@ def _flip_cover(Wg, Wo, tol):
     return int(cols.sum() + rows.sum())
 
 
+@pytest.mark.parametrize("compute", ["auto", "fp32"])
+def test_config2_reference_sequential_fit_with_score(gpu_device, capsys, compute):
+    """RBM.fit as the reference runs it (rbm.py:214-234) at the configs[1] size: per step three K.function calls = three
+    independent chains applied in sequence (update_mode 'reference_sequential'), then the free-energy score of a fourth
+    chain, printed; two steps of 4096 rows.  Against oracle.fit: parameters equal outside the rows / columns a borderline
+    sample explains, scores to 1e-3."""
+    from keras_unsupervised_amd.ebm import MODE_VISIBLE_BERNOULLI, RBM
+    nv, nh, N, bs, lr = 784, 1024, 8192, 4096, 1e-4
+    W0 = synthetic_params(nv, nh, seed=1)
+    V = synthetic_binary(N, nv, seed=97)
+    hps = {"batch_size": bs, "epochs": 1, "lr": lr}
+    r = RBM(hps, nh, name="rbm_1", mode=MODE_VISIBLE_BERNOULLI, seed=5, update_mode="reference_sequential", weights=W0,
+            compute_dtype=compute)
+    assert r.fit(V) is None                                                  # verbose = 1: the reference's default
+    out = capsys.readouterr().out
+    assert "1 / 1  epochs" in out and "2/2, score:" in out                   # rbm.py:115, :234
+    Wo, bho, bvo, scores, nstep = O.fit(*W0, V, hps, seed=5, update_mode="reference_sequential", with_score=True)
+    assert nstep == 2 and len(r.last_scores) == 2
+    Wg, bhg, bvg = r.get_weights()
+    assert _flip_cover(Wg, Wo, TOL) <= 48
+    assert np.mean(np.abs(bhg - bho) > TOL) <= 0.03 and np.mean(np.abs(bvg - bvo) > TOL) <= 0.03
+    assert np.linalg.norm(Wg - Wo) <= 1e-3 * np.linalg.norm(Wo - W0[0])
+    for a, b in zip(r.last_scores, scores):
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (r.last_scores, scores)
+
+
 def test_config4_dbn_784_1024_1024_1024(gpu_device, capsys):
     """configs[3]: greedy layer-wise CD-1 (dbn.py:34-55), B = 4096, two parameter updates per layer, through the class
     surface.  Per layer, teacher-forced on the activations the GPU stack produced: parameters against O.OracleLayer.fit
