@@ -19,12 +19,11 @@ using namespace kurbm;
 // Experiment knobs.  Every one is read from the environment ONCE, at kurbm_ctx_create, into the context (no getenv on
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
-enum { KN_LDPAD, KN_X3_BN, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
+enum { KN_LDPAD, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
        KN_UNFUSED_MIRROR, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
-    {"KURBM_X3_BN", 128},          // 64: 128 x 64 x3 tiles, two workgroups per CU
     {"KURBM_BF16_SPLIT", KN_AUTO}, // split-K slices of the bf16 / x3 statistics GEMM
     {"KURBM_X3_FULL", 0},          // 1: all nine piece pairs of a real x real product
     {"KURBM_X3_TALL", KN_AUTO},    // 0 / 1: never / always 256 x 64 half-step tiles
@@ -597,12 +596,11 @@ struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_spli
 // number of k positions
 static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, int s_max = 1 << 30) {
     OuterPlanB pl;
-    const bool bn64 = ctx->knob[KN_X3_BN] == 64;
     pl.gm = ceil_div(n_vis, 128);
-    pl.gn = ceil_div(n_hid, bn64 ? 64 : 128);
+    pl.gn = ceil_div(n_hid, 128);
     pl.nkt = round_up(rows, 128) / 64;
     pl.kt_total = nseg * pl.nkt;
-    int s = ctx->knob[KN_BF16_SPLIT] != KN_AUTO ? ctx->knob[KN_BF16_SPLIT] : ((bn64 ? 2 : 1) * ctx->ncu) / (pl.gm * pl.gn);
+    int s = ctx->knob[KN_BF16_SPLIT] != KN_AUTO ? ctx->knob[KN_BF16_SPLIT] : ctx->ncu / (pl.gm * pl.gn);
     if (s > s_max) s = s_max;
     if (s < 1) s = 1;
     if (s > pl.nkt) s = pl.nkt;
@@ -689,6 +687,7 @@ struct HalfOutB {
     int out_pieces = 1; size_t out_plane = 0;             // (x3, real-valued plane: its three pieces)
     uint16_t* outT = nullptr; int ldoT = 0;               // ... transposed
     int outT_pieces = 1; size_t outT_plane = 0;
+    bool outT_neg = false;                                // the transposed plane is stored negated
     float* out_f32 = nullptr; float* prob_f32 = nullptr; float* out_u = nullptr; int ldo32 = 0;
     float* colpart = nullptr; int ld_colpart = 0;
     float colsign = 1.f;                                  // x3: colpart = colsign * column sums of the value plane
@@ -709,7 +708,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip); rounded bf16: against its one piece
         g.nseg = pb_codes(ctx, a_pieces, m.pieces, 0u, &g.seg_codes, 0);
         g.pb_max = m.pieces;
-        g.cfg = ctx->knob[KN_X3_BN] == 64 ? 1 : 0;     // 1: 128 x 64 tiles, 256 threads, two workgroups per CU
+        g.cfg = 0;
         // 2: 256 x 64 tiles (fewer bytes per k-tile).  Whole 256-row tiles only: the bias partial rows are laid out
         // per 64 rows, two per 128-row tile, and an even number of those is what both tilings agree on
         const int tall = ctx->knob[KN_X3_TALL];
@@ -727,6 +726,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.out = o.out; g.ldo = o.ldo; g.ldo_cols = o.out ? o.ldo : g.N;
         g.out_pieces = o.out_pieces; g.out_plane = o.out_plane;
         g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
+        g.outT_neg = o.outT_neg ? 1 : 0;
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
         g.colpart = o.colpart; g.ld_colpart = o.ld_colpart; g.colsign = o.colsign;
         // row tiles fastest: an XCD's run of workgroups then shares ONE column tile, whose weight pieces
@@ -875,17 +875,18 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             h_cur = w.h2b;
         }
     }
-    // h_neg = sigmoid(v_neg.W + b_h), probabilities (rbm.py:124): only its transposed image is needed
+    // h_neg = sigmoid(v_neg.W + b_h), probabilities (rbm.py:124): only its transposed image is needed, and only by the
+    // statistics GEMM, where it enters with a minus sign: it is stored as -h_neg
     if (KURBM_STAGE(3)) {
         HalfOutB ho;
-        ho.outT = w.hnT; ho.ldoT = w.Lb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT;
+        ho.outT = w.hnT; ho.ldoT = w.Lb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT; ho.outT_neg = true;
         ho.colpart = w.part_h + (size_t)2 * ceil_div(rows, 128) * w.ldh32; ho.ld_colpart = w.ldh32; ho.colsign = -1.f;
         ho.grid_m_out = &gm_h;
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st))) return e;
     }
 
     // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
-    // segments: (piece of v_pos) x h_pos, then v_neg x (piece of h_neg), negated
+    // segments: (piece of v_pos) x h_pos, then v_neg x (piece of -h_neg)
     const int nseg_st = pieces == 3 ? v_pieces + vn_pieces : 2;
     const OuterPlanB plf = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, nseg_st);
     const int Mr = m_hi - m_lo;                         // visible rows of this call (all of them unless only == 7)
@@ -911,7 +912,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.pb_max = pieces;
         g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
         g.m_fastest = ctx->knob[KN_X3_STATS_MFAST];
-        g.cfg = ctx->knob[KN_X3_BN] == 64 ? 1 : 0;
+        g.cfg = 0;
         g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
         g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
         HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));

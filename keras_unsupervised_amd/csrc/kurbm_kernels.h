@@ -112,9 +112,10 @@ struct FinishArgs {
 
 // bf16 NT GEMM (k_gemm_pb, kurbm_x3.hip): A [M][lda], B [N][ldb] bf16, k contiguous and zero-padded to 128.
 // The k range is a list of up to MAX_SEG SEGMENTS of K elements each.  Segment s multiplies piece ia of
-// operand set `neg` of A with pieces 0 .. npb-1 of the same set of B (pieces = the bf16 hi / mid / lo parts of an
-// fp32 plane, `*_plane` elements apart; one piece on the rounded-bf16 path); set 1 enters negated (the negative phase
-// of the statistics).  seg_codes packs one 5-bit code per segment: bits 0-1 ia, bits 2-3 npb, bit 4 set.
+// operand set 0 or 1 of A with pieces 0 .. npb-1 of the same set of B (pieces = the bf16 hi / mid / lo parts of an
+// fp32 plane, `*_plane` elements apart; one piece on the rounded-bf16 path); set 1 is the negative phase of the
+// statistics, whose B planes (h_neg, transposed) are stored negated by the half step that makes them (outT_neg).
+// seg_codes packs one 5-bit code per segment: bits 0-1 ia, bits 2-3 npb, bit 4 set.
 constexpr int MAX_SEG = 12;
 struct GemmArgsB {
     const uint16_t* A0;
@@ -141,7 +142,7 @@ struct GemmArgsB {
     int nseg, nkt, kt_total, kt_per_split, nsplit;
     int grid_m, grid_n;
     int m_fastest;
-    int cfg;              // 0: 128 x 128 tile; 1: 128 x 64 (two workgroups per CU); 2: 256 x 64 (half steps)
+    int cfg;              // 0: 128 x 128 tile; 2: 256 x 64 (half steps)
     // half-step epilogue
     const float* bias;
     int act, noise;
@@ -154,6 +155,8 @@ struct GemmArgsB {
     uint16_t* outT;       // bf16 [N][ldoT]  the same plane transposed; nullable
     int ldoT;
     int outT_pieces;      // 1: outT = round-to-nearest bf16; 3: exact hi / mid / lo pieces, outT_plane apart
+    int outT_neg;         // the transposed plane holds MINUS the value plane (h_neg: the negative phase of the statistics
+                          // is then a plain product -- no sign handling between memory and the MFMAs)
     size_t outT_plane;
     float* out_f32;       // fp32 copy of the value plane (persistent chain, tests); nullable
     float* prob_f32;      // fp32 probabilities next to a sampled plane (tests); nullable

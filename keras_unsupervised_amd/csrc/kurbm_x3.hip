@@ -10,7 +10,7 @@
 // (kurbm_bf16.hip) that is a third fewer bytes from L2 and through LDS per MFMA.
 //
 // Segments (GemmArgsB::seg_codes): segment s multiplies piece `ia` of A (set 0 or 1) with pieces
-// 0 .. npb-1 of B of the same set; set 1 enters negated (negative phase of the statistics).  A
+// 0 .. npb-1 of B of the same set; set 1 is the negative phase of the statistics (its B planes are stored negated).  A
 // real-valued A (grey-level data) is three segments (ia = 0, 1, 2 with npb = 3, 2, 1).
 //
 // Tile 128 x 128, k-tile 64 (swizzled 128-byte LDS rows), 8 waves (2 x 4, 64 x 32 outputs each), two per SIMD: while one waits for
@@ -63,15 +63,15 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define KURBM_STAMP(var) do { } while (0)
 #endif
 
-// WS ("wave specialised"): four LOADER waves beside the eight MFMA waves (768 threads, three waves per SIMD).  The loaders
-// do all the staging (global -> registers -> LDS) in a loop of their own; the MFMA waves only read fragments, issue MFMAs
-// and meet the loaders at the tile's barrier.  A stall of a staging instruction (VMEM issue, the wait for a load, the
-// ds_write path) then never sits in the instruction stream of a wave that has MFMAs to issue: with staging in the MFMA
-// waves the k loop took twice the time of its MFMAs alone (ablation build), wherever in the tile the staging was put.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int PB, int EPI, int NOISE, bool WS = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 * WAVES_M * WAVES_N + 256) / 256 : 2) void k_gemm_pb(GemmArgsB g) {
+// Wave-specialised: four LOADER waves beside the eight MFMA waves (768 threads, three waves per SIMD).  The loaders do all
+// the staging in a loop of their own -- LDS-DMA, `buffer_load_dwordx4 ... lds`: no register and no ds_write between memory
+// and LDS -- and the MFMA waves only read fragments, issue MFMAs and meet the loaders at the tile's barrier.  A stall of a
+// staging instruction then never sits in the instruction stream of a wave that has MFMAs to issue: with staging in the
+// MFMA waves the k loop took twice the time of its MFMAs alone (round 1), wherever in the tile the staging was put.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int PB, int EPI, int NOISE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES_N + 256) / 256) void k_gemm_pb(GemmArgsB g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;          // threads of the MFMA waves (and of every epilogue loop)
-    constexpr int NTS = WS ? 256 : NT;                  // threads that stage tiles
+    constexpr int NTS = 256;                            // threads of the loader waves
     // LDS rows are the bare 128-byte k-tile, their eight 16-byte chunks XOR-swizzled with (row >> 1) & 7.
     // ds_read_b128 is served in groups of 16 lanes that are NOT consecutive ({0-3, 12-15, 20-27}, ...;
     // MI355X_MICROARCH.md, LDS): for an MFMA fragment read (lane = row l15, k chunk `slot`) a group is 8 rows at
@@ -87,15 +87,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int A_BYTES = BM * ROWB, B1_BYTES = BN * ROWB, B_BYTES = PB * B1_BYTES;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int NA = BM * CPR / NTS, NB1 = BN * CPR / NTS;   // 16-B chunks per staging lane: A tile, ONE piece of B
+    constexpr int NA = BM * CPR / NTS, NB1 = BN * CPR / NTS;   // 1-KiB pieces per loader wave: A tile, ONE piece of B
     static_assert((BM * CPR) % NTS == 0 && (BN * CPR) % NTS == 0, "whole chunks per lane");
     constexpr int PROW16 = 2 * BN + 16;   // bf16 patch row (bytes)
     constexpr int PROW32 = 4 * BN + 16;   // fp32 patch row (bytes)
     constexpr int PATCH_BYTES = (EPI == EPI_SOFTPLUS) ? WAVES_N * BM * 4 : BM * (EPI == EPI_SLAB ? PROW32 : PROW16);
     constexpr int SMEM_BYTES = (2 * STAGE > PATCH_BYTES) ? 2 * STAGE : PATCH_BYTES;
-    // WS: the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
+    // the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
     // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
-    constexpr int NI_LDS = (WS && EPI == EPI_HALFSTEP && NOISE == NOISE_BERNOULLI) ? 1 : 0;
+    constexpr int NI_LDS = (EPI == EPI_HALFSTEP && NOISE == NOISE_BERNOULLI) ? 1 : 0;
     constexpr int DRAW_LDS_BYTES = NI_LDS * TM * NT * 16;
     static_assert(SMEM_BYTES + DRAW_LDS_BYTES <= 160 * 1024, "LDS per workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES + DRAW_LDS_BYTES];
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = WS && wave >= NT / 64;          // wave-uniform role
-    const int stid = WS ? (tid & 255) : tid;            // staging thread id
+    const bool loader = wave >= NT / 64;                // wave-uniform role
+    const int stid = tid & 255;                         // loader thread id
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l15 = lane & 15, slot = lane >> 4;
 #ifdef KURBM_STAMPS
@@ -157,37 +157,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
     //  writes that plane's zeros)
     const int nt = (t_end > t_begin && !(EPI == EPI_HALFSTEP && n0 >= g.N)) ? t_end - t_begin : 0;
 
-    // Staging map: chunk q -> (row q / CPR, 16-B chunk q % CPR); rows outside the matrix are pointed at
-    // row 0 (they only feed outputs that are never stored).  Loads are buffer loads: a per-lane BYTE
-    // offset that never changes (voffset) plus a per-tile scalar offset (soffset) against one descriptor
-    // per operand -- no per-tile vector address arithmetic at all.
+    // Staging map of the loader waves.  A wave instruction of LDS-DMA writes 1 KiB of LDS linearly (lane l -> bytes
+    // 16 l ...): piece q = 8 rows of a tile, lane l fills chunk slot l % 8 of row 8 q + l / 8.  The swizzle therefore
+    // sits on the SOURCE: the lane that fills slot ch of a row fetches chunk ch ^ key(row) of that row, the same
+    // involution as the fragment reads.  Rows outside the matrix are pointed at row 0 (they only feed outputs that
+    // are never stored).  Loads are buffer loads: a per-lane BYTE offset that never changes (voffset) plus a per-tile
+    // scalar offset (soffset) against one descriptor per operand -- no per-tile vector address arithmetic at all.
     unsigned goffA[NA], goffB[NB1];
-    int soffA[NA], soffB[NB1];
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
         const int q = it * NTS + stid, row = q / CPR, ch = q % CPR;
         const int x = (m0 + row < g.M) ? m0 + row : 0;
-        goffA[it] = 2u * (unsigned)(x * g.lda + 8 * ch);
-        soffA[it] = row * ROWB + 16 * (ch ^ ((row >> 1) & 7));
+        goffA[it] = 2u * (unsigned)(x * g.lda + 8 * (ch ^ ((row >> 1) & 7)));
     }
 #pragma unroll
     for (int it = 0; it < NB1; ++it) {
         const int q = it * NTS + stid, row = q / CPR, ch = q % CPR;
         const int x = (n0 + row < g.N) ? n0 + row : 0;
-        goffB[it] = 2u * (unsigned)(x * g.ldb + 8 * ch);
-        soffB[it] = row * ROWB + 16 * (ch ^ ((row >> 1) & 7));
+        goffB[it] = 2u * (unsigned)(x * g.ldb + 8 * (ch ^ ((row >> 1) & 7)));
     }
-    constexpr bool SIGNED = (EPI == EPI_SLAB);
     typedef __amdgpu_buffer_rsrc_t rsrc_t;
     // B: one descriptor for both operand sets (they live in one workspace), a set is a scalar offset.  A: one descriptor
     // PER SET -- set 0 of the statistics GEMM (the v_pos planes) may sit in the caller's resident data planes, any distance
     // from the workspace that holds set 1 -- picked per tile by a scalar select.
-    const rsrc_t dA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.A0), 0, 0xFFFFFFFF, 0x00020000);
-    const rsrc_t dA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.A1 ? g.A1 : g.A0), 0, 0xFFFFFFFF, 0x00020000);
-    const rsrc_t dB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.baseB), 0, 0xFFFFFFFF, 0x00020000);
+    [[maybe_unused]] const rsrc_t dA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.A0), 0, 0xFFFFFFFF, 0x00020000);
+    [[maybe_unused]] const rsrc_t dA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.A1 ? g.A1 : g.A0), 0, 0xFFFFFFFF, 0x00020000);
+    [[maybe_unused]] const rsrc_t dB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.baseB), 0, 0xFFFFFFFF, 0x00020000);
 
     // a tile: the scalar byte offsets of its A rows and of piece 0 of its B rows
-    struct TileRef { uint32_t oa, ob, bplane; uint32_t flip; int npb; bool neg; };
+    struct TileRef { uint32_t oa, ob, bplane; int npb; bool neg; };
     auto tile_of = [&](int t) __attribute__((always_inline)) {
         TileRef r;
         t = t < t_end ? t : t_end - 1;
@@ -206,77 +204,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
         r.neg = __builtin_amdgcn_readfirstlane((int)neg) != 0;
         r.ob = __builtin_amdgcn_readfirstlane((neg ? g.offB1 : g.offB0) + k0);
         r.bplane = __builtin_amdgcn_readfirstlane(2u * (uint32_t)(neg ? g.b_plane1 : g.b_plane0));
-        r.flip = neg ? 0x80008000u : 0u;   // sign bits of a bf16 pair: set 1 enters negated
         r.npb = __builtin_amdgcn_readfirstlane((int)((code >> 2) & 3u));
         return r;
-    };
-
-    struct Regs { u32x4 a[NA], b[PB][NB1]; };   // one tile between global memory and LDS (two of them in flight)
-    // branch-free: a piece the segment does not use is fetched from the last one it does (same lines)
-    // part 0 = the A chunks, part 1 + p = piece p of B.  The L1 path takes ~16 cycles per 1-KiB wave load (64 B/clk per
-    // CU): the eight loads of a tile issued back to back by all eight waves stall the later waves for ~1000 cycles,
-    // so the k loop issues one part per micro-step.
-    auto fetch_part = [&](Regs& R, const TileRef& r, int part) __attribute__((always_inline)) {
-#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 1)
-        return;   // timing-only build: no global loads (the registers keep whatever they hold)
-#endif
-        if (part == 0) {
-#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 4)
-            constexpr int NAL = NA / 2;   // timing-only build: an A tile of bytes is half the chunks
-#else
-            constexpr int NAL = NA;
-#endif
-            if (r.neg) {   // (wave-uniform)
-#pragma unroll
-                for (int it = 0; it < NAL; ++it)
-                    R.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA1, goffA[it], r.oa, 0));
-            } else {
-#pragma unroll
-                for (int it = 0; it < NAL; ++it)
-                    R.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dA0, goffA[it], r.oa, 0));
-            }
-        } else {
-            const int p = part - 1;
-            const uint32_t so = __builtin_amdgcn_readfirstlane(r.ob + (uint32_t)(p < r.npb ? p : r.npb - 1) * r.bplane);
-#pragma unroll
-            for (int it = 0; it < NB1; ++it)
-                R.b[p][it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dB, goffB[it], so, 0));
-        }
-    };
-    auto fetch = [&](Regs& R, const TileRef& r) __attribute__((always_inline)) {
-#pragma unroll
-        for (int part = 0; part <= PB; ++part) fetch_part(R, r, part);
-    };
-    // park chunks [c0, c1) of the tile held in R: chunk order = A, piece 0 of B, piece 1, ...
-    constexpr int NCH = NA + PB * NB1;
-    auto park = [&](const Regs& R, int buf, const TileRef& r, int c0, int c1) __attribute__((always_inline)) {
-        unsigned char* a = smem + buf * STAGE;
-        unsigned char* b = a + A_BYTES;
-#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 2)
-        // timing-only build: no LDS writes; every load stays live and is waited for here
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c < c0 || c >= c1) continue;
-            if (c < NA) asm volatile("" :: "v"(R.a[c]));
-            else asm volatile("" :: "v"(R.b[(c - NA) / NB1][(c - NA) % NB1]));
-        }
-        return;
-#endif
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c < c0 || c >= c1) continue;
-            if (c < NA) {
-#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 4)
-                if (c >= NA / 2) continue;
-#endif
-                u32x4 v = R.a[c];
-                if (SIGNED) { v.x ^= r.flip; v.y ^= r.flip; v.z ^= r.flip; v.w ^= r.flip; }
-                *reinterpret_cast<u32x4*>(a + soffA[c]) = v;
-            } else {
-                const int p = (c - NA) / NB1, it = (c - NA) % NB1;
-                if (p < r.npb) *reinterpret_cast<u32x4*>(b + p * B1_BYTES + soffB[it]) = R.b[p][it];
-            }
-        }
     };
 
     f32x4 acc[TM][TN];
@@ -290,15 +219,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
     const int swz = (l15 >> 1) & 7;
     auto frag_a = [&](int buf, int ks, u32x4 (&f)[TM]) __attribute__((always_inline)) {
         const unsigned char* c = smem + buf * STAGE + (wm * WM + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
-#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 4)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {   // timing-only: 8 bytes per fragment, expanded by four v_perm_b32
-            const u32x2 raw = *reinterpret_cast<const u32x2*>(c + mi * 16 * ROWB);
-            f[mi] = u32x4{__builtin_amdgcn_perm(0u, raw.x, 0x010C000Cu), __builtin_amdgcn_perm(0u, raw.x, 0x030C020Cu),
-                          __builtin_amdgcn_perm(0u, raw.y, 0x010C000Cu), __builtin_amdgcn_perm(0u, raw.y, 0x030C020Cu)};
-        }
-        return;
-#endif
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
     };
@@ -316,12 +236,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
                     __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
     };
 
-    // One tile with NPB pieces = KS * NPB micro-steps (k-step ks = u / NPB, piece p = u % NPB), pipelined:
-    //   u = 0           request tile i+2 from global memory (registers L)
-    //   middle steps    park tile i+1 (registers P, requested a whole tile ago) in the other LDS buffer
-    //   last step       the tile's ONLY barrier, then read the NEXT tile's first fragments
-    // Every micro-step's fragment reads are issued one step ahead of the MFMAs that use them.
-    auto one_tile = [&](const int cur, Regs& L, const Regs& P, const TileRef& rp, const TileRef& r2, auto npb_tag) __attribute__((always_inline)) {
+    // One tile with NPB pieces = KS * NPB micro-steps (k-step ks = u / NPB, piece p = u % NPB).  Every micro-step's
+    // fragment reads are issued one step (three-piece tiles: two steps) ahead of the MFMAs that use them; the last
+    // micro-step holds the tile's ONLY barrier (behind it the loaders have the next tile in the other LDS buffer), then
+    // reads the NEXT tile's first fragments.
+    auto one_tile = [&](const int cur, auto npb_tag) __attribute__((always_inline)) {
         constexpr int NPB = decltype(npb_tag)::value;
         constexpr int NU = KS * NPB;
 #ifdef KURBM_STAMPS
@@ -331,19 +250,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!WS) {
-                if constexpr (NU > PB) {   // one part of tile i+2 per micro-step
-                    if (u <= PB) fetch_part(L, r2, u);
-                } else {
-                    if (u == 0) fetch(L, r2);
-                }
-                if constexpr (NU >= 4) {   // parks spread over the middle micro-steps
-                    constexpr int NMID = NU - 2;
-                    if (u >= 1 && u <= NMID) park(P, cur ^ 1, rp, (u - 1) * NCH / NMID, u * NCH / NMID);
-                } else {
-                    if (u == 0) park(P, cur ^ 1, rp, 0, NCH);
-                }
-            }
             const int ks = u / NPB;
             if constexpr (NPB == 3) {
                 // fragments are read TWO micro-steps ahead (an LDS read under load takes longer than the 8 MFMAs
@@ -383,18 +289,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto tile_any = [&](const int cur, Regs& L, const Regs& P, int npb, const TileRef& rp, const TileRef& r2) __attribute__((always_inline)) {
-        if (PB >= 3 && npb == 3) one_tile(cur, L, P, rp, r2, std::integral_constant<int, 3>{});
-        else if (PB >= 2 && npb == 2) one_tile(cur, L, P, rp, r2, std::integral_constant<int, 2>{});
-        else one_tile(cur, L, P, rp, r2, std::integral_constant<int, 1>{});
+    auto tile_any = [&](const int cur, int npb) __attribute__((always_inline)) {
+        if (PB >= 3 && npb == 3) one_tile(cur, std::integral_constant<int, 3>{});
+        else if (PB >= 2 && npb == 2) one_tile(cur, std::integral_constant<int, 2>{});
+        else one_tile(cur, std::integral_constant<int, 1>{});
     };
 
-    // The Philox words of this lane's outputs do not depend on the GEMM.  Those of its first DRAW_EARLY output
-    // columns are drawn while the first two tiles are on their way from memory (the vector ALU is idle then; more
-    // calls than that wait would cover only lengthen the prologue), the rest in the epilogue.
-    constexpr int DRAW_EARLY = WS ? 0 : (TN + 1) / 2;   // (three waves per SIMD leave 168 registers: none to hold draws over the loop)
+    // The Philox words of this lane's outputs do not depend on the GEMM: those of its first NI_LDS output columns are drawn
+    // in the prologue and parked in LDS (three waves per SIMD leave 168 registers: none to hold draws over the loop), the
+    // rest in the epilogue.
     uint32_t draws[(NOISE != NOISE_NONE) ? TM * TN : 1][4];
-    auto draw_cols = [&](int ni0, int ni1, bool pin) __attribute__((always_inline)) {
+    auto draw_cols = [&](int ni0, int ni1) __attribute__((always_inline)) {
         if (NOISE == NOISE_NONE) return;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
@@ -405,7 +310,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
                 uint32_t (&w)[4] = draws[(NOISE != NOISE_NONE) ? ni * TM + mi : 0];
                 philox4x32_10((uint32_t)(n0 + wn * WN + l15 + ni * 16), (uint32_t)(grow >> 2), g.rng.stream_id, g.rng.step,
                               g.rng.seed_lo, g.rng.seed_hi, w);
-                if (pin) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));   // drawn HERE, not sunk into the epilogue
             }
     };
     float biasv[TN];   // loaded here too: in the epilogue its latency would be exposed
@@ -414,33 +318,59 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
         const int c = n0 + wn * WN + l15 + ni * 16;
         biasv[ni] = (EPI == EPI_HALFSTEP && c < g.N) ? g.bias[c] : 0.f;
     }
-    if (WS && loader) {
-        // ---- loader waves: their own loop and registers; one barrier per tile, like the MFMA waves
+    if (loader) {
+        // ---- loader waves: a loop of their own; one barrier per tile, like the MFMA waves.  `buffer_load_dwordx4 ... lds`,
+        // one 1-KiB piece (8 rows of a tile) per wave instruction, straight into the stage that the barrier before has
+        // freed; the wait for a tile's pieces and then the tile's barrier make them visible to the MFMA waves
+        // (cdna_hip_programming.md 5, "Read a staged buffer one phase AFTER the wait that retires it").
         if (nt > 0) {
-            Regs r0, r1;
-            TileRef rc = tile_of(t_begin), rn = tile_of(t_begin + 1);
-            fetch(r0, rc);
-            park(r0, 0, rc, 0, NCH);
-            fetch(r1, rn);
-            __syncthreads();
-            int i = 0;
-            for (; i + 1 < nt; i += 2) {
-                TileRef r2 = tile_of(t_begin + i + 2);
-                fetch(r0, r2);
-                park(r1, 1, rn, 0, NCH);
-                __syncthreads();
-                rn = r2;
-                r2 = tile_of(t_begin + i + 3);
-                fetch(r1, r2);
-                park(r0, 0, rn, 0, NCH);
-                __syncthreads();
-                rn = r2;
+            auto dma_tile = [&](int buf, const TileRef& r) __attribute__((always_inline)) {
+#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 1)
+                return;   // timing-only build: no global loads
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass drops a kernel's launch stub over the LDS address-space cast)
+                typedef __attribute__((address_space(3))) void* lds_ptr;
+                const int lw = wave - NT / 64;
+                unsigned char* a = smem + buf * STAGE + lw * 8 * ROWB;
+                if (r.neg) {   // (wave-uniform)
+#pragma unroll
+                    for (int it = 0; it < NA; ++it)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(dA1, (lds_ptr)(a + it * 32 * ROWB), 16, goffA[it], r.oa, 0, 0);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < NA; ++it)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(dA0, (lds_ptr)(a + it * 32 * ROWB), 16, goffA[it], r.oa, 0, 0);
+                }
+#pragma unroll
+                for (int p = 0; p < PB; ++p) {
+                    if (p >= r.npb) break;   // (wave-uniform)
+                    const uint32_t so = r.ob + (uint32_t)p * r.bplane;
+#pragma unroll
+                    for (int it = 0; it < NB1; ++it)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(dB, (lds_ptr)(a + A_BYTES + p * B1_BYTES + it * 32 * ROWB), 16, goffB[it], so, 0, 0);
+                }
+#endif
+            };
+            // raw barriers and explicit waits: `s_waitcnt` with expcnt / lgkmcnt not waited for, vmcnt in bits 3:0 and 15:14
+            constexpr int VM0 = 0x0F70;
+            auto vm = [](int n) constexpr { return VM0 | (n & 15) | ((n >> 4) << 14); };
+            // both stages are free at the start: tiles 0 and 1 are requested back to back, and the first barrier waits for
+            // tile 0's pieces only (a counted vmcnt leaves tile 1's in flight)
+            dma_tile(0, tile_of(t_begin));
+            if (nt > 1) {
+                const TileRef t1 = tile_of(t_begin + 1);
+                dma_tile(1, t1);
+                if (t1.npb >= 3) __builtin_amdgcn_s_waitcnt(vm(NA + 3 * NB1));
+                else if (t1.npb == 2) __builtin_amdgcn_s_waitcnt(vm(NA + 2 * NB1));
+                else __builtin_amdgcn_s_waitcnt(vm(NA + NB1));
+            } else {
+                __builtin_amdgcn_s_waitcnt(VM0);
             }
-            if (i < nt) {
-                const TileRef r2 = tile_of(t_begin + i + 2);
-                fetch(r0, r2);
-                park(r1, 1, rn, 0, NCH);
-                __syncthreads();
+            __builtin_amdgcn_s_barrier();
+            for (int i = 0; i < nt; ++i) {
+                if (i >= 1 && i + 1 < nt) dma_tile((i + 1) & 1, tile_of(t_begin + i + 1));
+                __builtin_amdgcn_s_waitcnt(VM0);
+                __builtin_amdgcn_s_barrier();
             }
         }
         __syncthreads();
@@ -452,7 +382,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
         }
         return;
     }
-    Regs r0, r1;   // (never touched by the MFMA waves of the WS build: they stage nothing)
     if constexpr (NI_LDS > 0) {
         if (nt > 0) {
 #pragma unroll
@@ -467,34 +396,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
                 }
         }
     }
-    if (WS) __builtin_amdgcn_s_setprio(2);   // the MFMA waves go first wherever a loader wave competes for issue
+    __builtin_amdgcn_s_setprio(2);   // the MFMA waves go first wherever a loader wave competes for issue
     if (nt > 0) {
-        TileRef rc = tile_of(t_begin), rn = tile_of(t_begin + 1);
-        if (!WS) {
-            fetch(r0, rc);
-            fetch(r1, rn);
-        }
-        draw_cols(0, DRAW_EARLY, true);
-        if (!WS) park(r0, 0, rc, 0, NCH);
         __syncthreads();
         frag_a(0, 0, fa[0]);
         frag_b(0, 0, 0, fb[0]);
         KURBM_STAMP(ts[1]);
-        // unrolled by two: register sets and LDS buffers alternate statically.  Branch-free: past the
-        // end of the slice the last tile is fetched / parked again (in bounds, never read).
+        // unrolled by two: the LDS buffers alternate statically
         int i = 0;
         for (; i + 1 < nt; i += 2) {
-            TileRef r2 = tile_of(t_begin + i + 2);
-            tile_any(0, r0, r1, rc.npb, rn, r2);
-            rc = rn; rn = r2;
-            r2 = tile_of(t_begin + i + 3);
-            tile_any(1, r1, r0, rc.npb, rn, r2);
-            rc = rn; rn = r2;
+            tile_any(0, tile_of(t_begin + i).npb);
+            tile_any(1, tile_of(t_begin + i + 1).npb);
         }
-        if (i < nt) {
-            const TileRef r2 = tile_of(t_begin + i + 2);
-            tile_any(0, r0, r1, rc.npb, rn, r2);
-        }
+        if (i < nt) tile_any(0, tile_of(t_begin + i).npb);
     }
     __syncthreads();
     KURBM_STAMP(ts[2]);
@@ -585,9 +499,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
                         draws[ni * TM + mi][2] = w.z; draws[ni * TM + mi][3] = w.w;
                     }
             }
-            draw_cols(nt > 0 ? NI_LDS : 0, TN, false);
+            draw_cols(nt > 0 ? NI_LDS : 0, TN);
         } else {
-            draw_cols(nt > 0 ? DRAW_EARLY : 0, TN, false);
+            draw_cols(0, TN);
         }
         // (SIDE = the fp32 test planes are wanted: a compile-time tag, because a per-element test of g.side, however
         //  uniform, puts a branch between every two of the 32 sigmoids of a lane and serialises their latencies)
@@ -677,6 +591,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
     //     rows past M (k padding of the statistics GEMM) are written as zeros
     if (g.outT) {
         const int np = (g.outT_pieces == 3) ? 3 : 1;
+        const float tsign = g.outT_neg ? -1.f : 1.f;   // (the pieces of -x are minus the pieces of x)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int col = colb + ni * 16;
@@ -686,7 +601,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
                 if (col < g.N && rb < g.ldoT) {
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (rb + r < g.M) ? xv[mi][ni][r] : 0.f;
+                    for (int r = 0; r < 4; ++r) v[r] = (rb + r < g.M) ? tsign * xv[mi][ni][r] : 0.f;
                     uint16_t* dst = g.outT + (size_t)col * g.ldoT + rb;
                     for (int j = 0; j < np; ++j) {
                         u32x2 pk;
@@ -773,21 +688,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + (WS ? 256 : 0), WS ? (64 *
 // ------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------
-// one (pieces, epilogue, noise) combination: tile configuration by g.cfg (0: 128 x 128, 1: 128 x 64 two workgroups per CU,
-// 2: 256 x 64 half steps); only the combinations the host plans are instantiated
+// one (pieces, epilogue, noise) combination: tile configuration by g.cfg (0: 128 x 128; 2: 256 x 64, half steps only); only
+// the combinations the host plans are instantiated
 template <int PBN, int E, int NZ>
-static hipError_t launch_pb(const GemmArgsB& g, int nblk, int ws, hipStream_t st) {
+static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
     if (g.cfg == 2) {
-        if constexpr (E == EPI_HALFSTEP) hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+        if constexpr (E == EPI_HALFSTEP) hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ>), dim3(nblk), dim3(768), 0, st, g);
         else return hipErrorInvalidValue;
-    } else if (g.cfg == 1) {
-        if constexpr (PBN == 3) hipLaunchKernelGGL((k_gemm_pb<128, 64, 2, 2, 64, PBN, E, NZ>), dim3(nblk), dim3(256), 0, st, g);
-        else return hipErrorInvalidValue;
-    } else if (ws || PBN == 1) {
-        hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+    } else if (g.cfg == 0) {
+        hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ>), dim3(nblk), dim3(768), 0, st, g);
     } else {
-        if constexpr (PBN == 3) hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ>), dim3(nblk), dim3(512), 0, st, g);
-        else return hipErrorInvalidValue;
+        return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
@@ -819,7 +730,7 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
         if (on && nblk % 8 == 0) {
             int wa = 0, wb = 0;
             for (int sgm = 0; sgm < g.nseg; ++sgm) { wa += 1; wb += (int)((g.seg_codes >> (5 * sgm + 2)) & 3u); }
-            const int bmr = (g.cfg == 2) ? 256 : 128, bnr = g.cfg ? 64 : 128;
+            const int bmr = (g.cfg == 2) ? 256 : 128, bnr = (g.cfg == 2) ? 64 : 128;
             long long best = -1;
             for (int xz = 1; xz <= 8; xz *= 2)
                 for (int xr = 1; xr * xz <= 8; xr *= 2) {
@@ -830,12 +741,11 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
                 }
         }
     }
-    static const int ws = getenv("KURBM_X3_WS") ? atoi(getenv("KURBM_X3_WS")) : 1;
     // cfg 2: 256 x 64 tiles for the half steps (A tile 32 KB + three 8-KB pieces of B = 56 KB per k-tile instead of 64 KB
     // for the same MFMAs: the k loop moves with the bytes a CU takes in).  pb_max = 1: every segment has ONE piece of B (the
     // rounded-bf16 path, kurbm_cd_step_bf16): the same kernel with a k-tile of A + one B tile.
 #define KURBM_PB_ANY(PBN, E, NZ) \
-    if (epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) return launch_pb<PBN, E, NZ>(g, nblk, ws, st);
+    if (epi == E && (E != EPI_HALFSTEP || g.noise == NZ)) return launch_pb<PBN, E, NZ>(g, nblk, st);
     if (g.pb_max == 1) {
         KURBM_PB_ANY(1, EPI_HALFSTEP, NOISE_NONE)
         KURBM_PB_ANY(1, EPI_HALFSTEP, NOISE_BERNOULLI)
