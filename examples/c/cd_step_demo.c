@@ -50,20 +50,22 @@ int main(void) {
     HIP(hipMemcpy(r1, W, nW * 4, hipMemcpyDeviceToHost));
 
     /* x3 kernels: weight-piece mirror, workspace, resident data planes */
-    size_t mir_bytes = kurbm_x3_mirror_bytes(ctx, nv, nh), ws3_bytes = kurbm_x3_workspace_bytes(ctx, rows, nv, nh, 1, 1);
-    size_t pl_bytes = kurbm_x3_planes_bytes(ctx, rows, nv, 1);
+    size_t mir_bytes = kurbm_x3_mirror_bytes(ctx, nv, nh), ws3_bytes = kurbm_x3_workspace_bytes(ctx, rows, nv, nh, 1, 1 | KURBM_V_BINARY);
+    size_t pl_bytes = kurbm_x3_planes_bytes(ctx, rows, nv, 1 | KURBM_V_BINARY);
     void *mir, *ws3, *planes;
     int* flag;
     HIP(hipMalloc(&mir, mir_bytes)); HIP(hipMalloc(&ws3, ws3_bytes)); HIP(hipMalloc(&planes, pl_bytes)); HIP(hipMalloc((void**)&flag, 4));
     HIP(hipMemcpy(W, hW, nW * 4, hipMemcpyHostToDevice)); HIP(hipMemset(bh, 0, nh * 4)); HIP(hipMemset(bv, 0, nv * 4));
+    HIP(hipMemset(flag, 0, 4));
     KU(kurbm_bf16_exact(ctx, v, rows, nv, ld, flag, NULL));
-    int inexact = 1;
-    HIP(hipMemcpy(&inexact, flag, 4, hipMemcpyDeviceToHost));
-    if (inexact) { fprintf(stderr, "0/1 data reported as not bf16-exact\n"); return 4; }
+    int bits = 3;   /* bit 0: some value is not a bf16 value; bit 1: some value is neither 0 nor 1 */
+    HIP(hipMemcpy(&bits, flag, 4, hipMemcpyDeviceToHost));
+    if (bits) { fprintf(stderr, "0/1 data reported as %d\n", bits); return 4; }
+    const int vp = 1 | KURBM_V_BINARY;   /* 0/1 data: one bf16 piece, positive statistics on the fp8 matrix cores */
     KU(kurbm_x3_mirror_refresh(ctx, &p, mir, mir_bytes, NULL));
-    KU(kurbm_x3_convert_rows(ctx, v, rows, ld, nv, 1, planes, pl_bytes, NULL));
+    KU(kurbm_x3_convert_rows(ctx, v, rows, ld, nv, vp, planes, pl_bytes, NULL));
     o.v_planes = planes;
-    KU(kurbm_cd_step_x3(ctx, &p, mir, mir_bytes, v, 1, rows, ld, &o, 7, ws3, ws3_bytes, NULL));
+    KU(kurbm_cd_step_x3(ctx, &p, mir, mir_bytes, v, vp, rows, ld, &o, 7, ws3, ws3_bytes, NULL));
     HIP(hipDeviceSynchronize());
     HIP(hipMemcpy(r2, W, nW * 4, hipMemcpyDeviceToHost));
 

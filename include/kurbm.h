@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define KURBM_ABI_VERSION 2
+#define KURBM_ABI_VERSION 3
 
 typedef struct kurbm_ctx kurbm_ctx;
 typedef struct kurbm_comm kurbm_comm; /* one RCCL communicator + the library's comm stream and events, per GPU */
@@ -246,8 +246,13 @@ int kurbm_half_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
  * v_pieces: 1 promises that every element of v_batch (and of opts->v_chain) is exactly a bf16
  * value, which 0/1 data is (check with kurbm_bf16_exact); 3 splits the batch as well.  When both
  * operands of a product are split, the three pairs of pieces below 2^-24 of the product are left out.
+ * 1 | KURBM_V_BINARY additionally promises that every element of v_batch is 0.0 or 1.0 (bit 1 of kurbm_bf16_exact's flag
+ * clear): the positive statistics v_pos^T h_pos are then a 0/1 x 0/1 product, which the library runs on the fp8 matrix
+ * cores (exact: the operands are 0 or 1, the accumulation is fp32; twice the bf16 rate, half the bytes).  A window of
+ * resident planes (kurbm_x3_convert_rows) must be made and used with the same v_pieces value.
  * The mirror holds the pieces of W in both orientations and follows the rules of the bf16 mirror.
  */
+#define KURBM_V_BINARY 0x10
 size_t kurbm_x3_mirror_bytes(kurbm_ctx* ctx, int n_vis, int n_hid);
 int kurbm_x3_mirror_refresh(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                             kurbm_stream_t stream);
@@ -353,7 +358,8 @@ int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p,
                         const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks,
                         void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
 
-/* *flag (device int) := 1 if some element of x [rows][ld] is not exactly representable in bf16, else 0. */
+/* *flag (device int, zeroed by the caller) |= 1 if some element of x [rows][ld] is not exactly representable in bf16,
+ * |= 2 if some element is neither 0.0 nor 1.0.  0: v_pieces = 1 | KURBM_V_BINARY; 2: v_pieces = 1; else 3. */
 int kurbm_bf16_exact(kurbm_ctx* ctx, const float* x, int rows, int cols, int ld, int* flag,
                      kurbm_stream_t stream);
 

@@ -88,7 +88,8 @@ SIGNATURES = {
     "kurbm_cd_step_x3_dp": (_i, [_vp, _vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _vp, _sz, _vp]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+V_BINARY = 0x10          # KURBM_V_BINARY: OR into v_pieces = 1 for 0/1 data
 UNIQUE_ID_BYTES = 128
 
 _lib = None

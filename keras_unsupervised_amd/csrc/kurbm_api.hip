@@ -19,11 +19,12 @@ using namespace kurbm;
 // Experiment knobs.  Every one is read from the environment ONCE, at kurbm_ctx_create, into the context (no getenv on
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
-enum { KN_LDPAD, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
+enum { KN_LDPAD, KN_X3_F8POS, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
        KN_UNFUSED_MIRROR, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
+    {"KURBM_X3_F8POS", 1},         // 0: the positive statistics of 0/1 data stay on bf16 planes
     {"KURBM_BF16_SPLIT", KN_AUTO}, // split-K slices of the bf16 / x3 statistics GEMM
     {"KURBM_X3_FULL", 0},          // 1: all nine piece pairs of a real x real product
     {"KURBM_X3_TALL", KN_AUTO},    // 0 / 1: never / always 256 x 64 half-step tiles
@@ -594,19 +595,22 @@ struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_spli
 
 // the statistics GEMM on k_gemm_pb: k-tile 64, one workgroup per CU, nseg segments walked fastest, so a slice is a whole
 // number of k positions
-static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, int s_max = 1 << 30) {
+static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, int s_max = 1 << 30,
+                                  bool f8pos = false) {
     OuterPlanB pl;
     pl.gm = ceil_div(n_vis, 128);
     pl.gn = ceil_div(n_hid, 128);
-    pl.nkt = round_up(rows, 128) / 64;
-    pl.kt_total = nseg * pl.nkt;
+    // f8pos: the walk is in units of 128 k -- one fp8 tile of segment 0, two 64-deep tiles of every other segment
+    const int per = f8pos ? 2 * nseg - 1 : nseg;
+    pl.nkt = round_up(rows, 128) / (f8pos ? 128 : 64);
+    pl.kt_total = per * pl.nkt;
     int s = ctx->knob[KN_BF16_SPLIT] != KN_AUTO ? ctx->knob[KN_BF16_SPLIT] : ctx->ncu / (pl.gm * pl.gn);
     if (s > s_max) s = s_max;
     if (s < 1) s = 1;
     if (s > pl.nkt) s = pl.nkt;
     pl.nsplit_bound = s;
     pl.kt_per_split = ceil_div(pl.kt_total, s);
-    pl.kt_per_split = round_up(pl.kt_per_split, nseg);
+    pl.kt_per_split = round_up(pl.kt_per_split, per);
     pl.nsplit = ceil_div(pl.kt_total, pl.kt_per_split);
     pl.ld_slab = round_up(n_hid, 4);
     return pl;
@@ -688,6 +692,7 @@ struct HalfOutB {
     uint16_t* outT = nullptr; int ldoT = 0;               // ... transposed
     int outT_pieces = 1; size_t outT_plane = 0;
     bool outT_neg = false;                                // the transposed plane is stored negated
+    bool outT_f8 = false;                                 // the transposed plane of a 0/1 sample as fp8 bytes
     float* out_f32 = nullptr; float* prob_f32 = nullptr; float* out_u = nullptr; int ldo32 = 0;
     float* colpart = nullptr; int ld_colpart = 0;
     float colsign = 1.f;                                  // x3: colpart = colsign * column sums of the value plane
@@ -726,7 +731,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.out = o.out; g.ldo = o.ldo; g.ldo_cols = o.out ? o.ldo : g.N;
         g.out_pieces = o.out_pieces; g.out_plane = o.out_plane;
         g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
-        g.outT_neg = o.outT_neg ? 1 : 0;
+        g.outT_neg = o.outT_neg ? 1 : 0; g.outT_f8 = o.outT_f8 ? 1 : 0;
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
         g.colpart = o.colpart; g.ld_colpart = o.ld_colpart; g.colsign = o.colsign;
         // row tiles fastest: an XCD's run of workgroups then shares ONE column tile, whose weight pieces
@@ -800,7 +805,9 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     if (o->k < 1 || o->k > 15) return fail(KURBM_ERR_ARG, "k must be in [1, 15]");
     if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN)
         return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
-    if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1 or 3");
+    const bool v_binary = (v_pieces == (1 | KURBM_V_BINARY));
+    if (v_binary) v_pieces = 1;
+    if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1, 1 | KURBM_V_BINARY or 3");
     if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
     if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
     if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
@@ -818,6 +825,8 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     const bool need_w = (which & 1) || o->delta_out;
     // x3 with Gaussian visibles: v_t / v_neg are real-valued, so they travel as three pieces like real-valued data
     const int vn_pieces = (pieces == 3 && gauss) ? 3 : 1;
+    // 0/1 data on the x3 path: v_pos^T and h_pos^T leave as fp8 planes and their product runs on the fp8 matrix cores
+    const bool f8pos = v_binary && pieces == 3 && ctx->knob[KN_X3_F8POS] != 0;
     int e;
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
@@ -832,12 +841,12 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         w.vb = vp.vb; w.vbT = vp.vbT; part_v_pos = vp.part_v;
     } else if (KURBM_STAGE(0))
         HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Lv, w.Kb, w.vbT, w.Lb, p->n_vis, v_pieces, w.planeV,
-                                   w.planeVT, w.part_v, w.ldv32, st));
+                                   w.planeVT, w.part_v, w.ldv32, st, f8pos ? 1 : 0));
     // h_pos ~ p(h | v_pos)                                          rbm.py:120
     RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
     if (KURBM_STAGE(1)) {
         HalfOutB ho;
-        ho.out = w.hb; ho.ldo = w.Lh; ho.outT = w.hbT; ho.ldoT = w.Lb;
+        ho.out = w.hb; ho.ldo = w.Lh; ho.outT = w.hbT; ho.ldoT = w.Lb; ho.outT_f8 = f8pos;
         ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.colsign = 1.f;
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
     }
@@ -888,12 +897,12 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
     // segments: (piece of v_pos) x h_pos, then v_neg x (piece of -h_neg)
     const int nseg_st = pieces == 3 ? v_pieces + vn_pieces : 2;
-    const OuterPlanB plf = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, nseg_st);
+    const OuterPlanB plf = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, nseg_st, 1 << 30, f8pos);
     const int Mr = m_hi - m_lo;                         // visible rows of this call (all of them unless only == 7)
     const bool sub = (Mr != p->n_vis);
     // a row range keeps inside the slab memory carved for the whole matrix
     const OuterPlanB pl = sub ? plan_outer_bf16(ctx, rows, Mr, p->n_hid, nseg_st,
-                                                (int)((w.slab_stride * plf.nsplit_bound) / ((size_t)Mr * plf.ld_slab)))
+                                                (int)((w.slab_stride * plf.nsplit_bound) / ((size_t)Mr * plf.ld_slab)), f8pos)
                               : plf;
     const size_t slab_stride = sub ? (size_t)Mr * pl.ld_slab : w.slab_stride;
     int nslab_used = pl.nsplit;
@@ -911,6 +920,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.nseg = pb_codes(ctx, vn_pieces, pieces, 1u, &g.seg_codes, g.nseg);
         g.pb_max = pieces;
         g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
+        if (f8pos) { g.f8pos = 1; g.inv_nseg = inv_of(2 * g.nseg - 1); }   // (tiles per 128-deep unit)
         g.m_fastest = ctx->knob[KN_X3_STATS_MFAST];
         g.cfg = 0;
         g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
@@ -982,6 +992,7 @@ size_t kurbm_bf16_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid
 }
 size_t kurbm_x3_workspace_bytes(kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int k, int v_pieces) {
     (void)k;
+    if (v_pieces == (1 | KURBM_V_BINARY)) v_pieces = 1;
     if (!ctx || rows <= 0 || n_vis <= 0 || n_hid <= 0 || (v_pieces != 1 && v_pieces != 3)) return 0;
     return carve_bf16(ctx, nullptr, rows, n_vis, n_hid, 3, v_pieces).bytes;
 }
@@ -1025,6 +1036,7 @@ int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
     if (!ctx || !F) return fail(KURBM_ERR_ARG, "null argument");
     if (int e = check_params(p)) return e;
     if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
+    if (v_pieces == (1 | KURBM_V_BINARY)) v_pieces = 1;
     if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1 or 3");
     if (bad_matrix(v, ldv, p->n_vis)) return fail(KURBM_ERR_ARG, "v: null, misaligned, ld %% 4 != 0 or ld < n_vis");
     if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
@@ -1188,6 +1200,7 @@ int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
 }
 
 size_t kurbm_x3_planes_bytes(kurbm_ctx* ctx, int rows, int n_vis, int v_pieces) {
+    if (v_pieces == (1 | KURBM_V_BINARY)) v_pieces = 1;
     if (!ctx || rows <= 0 || n_vis <= 0 || (v_pieces != 1 && v_pieces != 3)) return 0;
     return carve_vplanes(ctx, nullptr, rows, n_vis, v_pieces).bytes;
 }
@@ -1195,6 +1208,9 @@ size_t kurbm_x3_planes_bytes(kurbm_ctx* ctx, int rows, int n_vis, int v_pieces) 
 int kurbm_x3_convert_rows(kurbm_ctx* ctx, const float* v, int rows, int ldv, int n_vis, int v_pieces, void* planes,
                           size_t planes_bytes, kurbm_stream_t stream) {
     if (!ctx) return fail(KURBM_ERR_ARG, "ctx is null");
+    // 0/1 data: the transposed plane (operand of the positive statistics only) as fp8, as the steps will read it
+    const bool f8 = (v_pieces == (1 | KURBM_V_BINARY)) && ctx->knob[KN_X3_F8POS] != 0;
+    if (v_pieces == (1 | KURBM_V_BINARY)) v_pieces = 1;
     if (rows <= 0 || n_vis <= 0 || (v_pieces != 1 && v_pieces != 3)) return fail(KURBM_ERR_ARG, "bad shape / v_pieces");
     if (bad_matrix(v, ldv, n_vis)) return fail(KURBM_ERR_ARG, "v: null, misaligned, ld %% 4 != 0 or ld < n_vis");
     if (!planes || !aligned16(planes)) return fail(KURBM_ERR_ARG, "planes is null or misaligned");
@@ -1202,7 +1218,7 @@ int kurbm_x3_convert_rows(kurbm_ctx* ctx, const float* v, int rows, int ldv, int
     if (vp.bytes > planes_bytes) return fail(KURBM_ERR_WORKSPACE, "planes too small: need %zu bytes, got %zu", vp.bytes, planes_bytes);
     const int Kb = round_up(rows, 128), Lv = ld_pad(ctx, round_up(n_vis, 128)), Lb = ld_pad(ctx, Kb);
     HIP_TRY(launch_f32_to_bf16(v, rows, n_vis, ldv, vp.vb, Lv, Kb, vp.vbT, Lb, n_vis, v_pieces, (size_t)Kb * Lv, (size_t)n_vis * Lb,
-                               vp.part_v, round_up(n_vis, 4), static_cast<hipStream_t>(stream)));
+                               vp.part_v, round_up(n_vis, 4), static_cast<hipStream_t>(stream), f8 ? 1 : 0));
     return KURBM_OK;
 }
 

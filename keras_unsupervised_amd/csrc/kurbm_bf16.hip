@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
                                                      uint16_t* __restrict__ out, int ldo, int out_rows,
                                                      uint16_t* __restrict__ outT, int ldoT, int outT_rows,
                                                      int pieces, size_t out_plane, size_t outT_plane,
-                                                     float* __restrict__ colpart, int ld_colpart) {
+                                                     float* __restrict__ colpart, int ld_colpart, int outT_f8) {
     __shared__ float tile[TR][CVT + 1];
     const int t = threadIdx.x;
     const int q4 = (t & 15) * 4, rq = t >> 4;           // 16 lanes x 4 elements across, 16 rows per pass
@@ -95,6 +95,13 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
 #pragma unroll
     for (int j = 0; j < CVT / CPP; ++j) {
         const int c = c0 + cq + CPP * j, r = r0 + rr4;    // outT[c][r .. r+3]
+        if (outT_f8) {   // 0/1 data: four fp8 bytes (1.0 = 0x38), row stride as for bf16
+            if (c < outT_rows && r < ldoT)
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(outT) + (size_t)c * ldoT * 2 + r) =
+                    (tile[rr4 + 0][cq + CPP * j] != 0.f ? 0x38u : 0u) | (tile[rr4 + 1][cq + CPP * j] != 0.f ? 0x3800u : 0u) |
+                    (tile[rr4 + 2][cq + CPP * j] != 0.f ? 0x380000u : 0u) | (tile[rr4 + 3][cq + CPP * j] != 0.f ? 0x38000000u : 0u);
+            continue;
+        }
         if (c < outT_rows && r < ldoT)                    // ldoT % 8 == 0
             store3(outT + (size_t)c * ldoT + r, outT_plane, tile[rr4 + 0][cq + CPP * j], tile[rr4 + 1][cq + CPP * j],
                    tile[rr4 + 2][cq + CPP * j], tile[rr4 + 3][cq + CPP * j]);
@@ -215,20 +222,27 @@ __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int ti
     }
 }
 
-// flag := 1 if some element of `in` is not exactly representable in bf16 (the caller zeroes it)
+// flag |= 1 if some element of `in` is not exactly representable in bf16, |= 2 if some element is neither 0.0 nor 1.0
+// (the caller zeroes it)
 __global__ __launch_bounds__(256) void k_bf16_exact_check(const float* __restrict__ in, int rows, int cols, int ld_in,
                                                           int* __restrict__ flag) {
     const int c4 = cols >> 2;   // ld % 4 == 0 and 16-B aligned rows: whole float4s, then the tail
-    bool bad = false;
+    bool bad = false, other = false;
+    auto look = [&](float x) {
+        const uint32_t b = __float_as_uint(x);
+        bad |= (b & 0xFFFFu) != 0u;
+        other |= (b != 0u) && (b != 0x3F800000u);
+    };
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
         const float* row = in + (size_t)r * ld_in;
         for (int c = threadIdx.x; c < c4; c += 256) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * c);
-            bad |= ((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) & 0xFFFFu) != 0u;
+            look(v.x); look(v.y); look(v.z); look(v.w);
         }
-        for (int c = 4 * c4 + threadIdx.x; c < cols; c += 256) bad |= (__float_as_uint(row[c]) & 0xFFFFu) != 0u;
+        for (int c = 4 * c4 + threadIdx.x; c < cols; c += 256) look(row[c]);
     }
-    if (bad) *flag = 1;
+    const int bits = (bad ? 1 : 0) | (other ? 2 : 0);
+    if (bits) atomicOr(flag, bits);
 }
 
 // ------------------------------------------------------------------------------------
@@ -236,7 +250,8 @@ __global__ __launch_bounds__(256) void k_bf16_exact_check(const float* __restric
 // ------------------------------------------------------------------------------------
 hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
                               uint16_t* outT, int ldoT, int outT_rows, int pieces, size_t out_plane, size_t outT_plane,
-                              float* colpart, int ld_colpart, hipStream_t st) {
+                              float* colpart, int ld_colpart, hipStream_t st, int outT_f8) {
+    if (outT_f8 && pieces != 1) return hipErrorInvalidValue;
     // cover the padded extents of whichever mirrors are requested
     int r_ext = rows, c_ext = cols;
     if (out) { if (out_rows > r_ext) r_ext = out_rows; if (ldo > c_ext) c_ext = ldo; }
@@ -246,11 +261,11 @@ hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, ui
     if (small) {
         dim3 grid((c_ext + CVT - 1) / CVT, (r_ext + 15) / 16);
         hipLaunchKernelGGL(k_f32_to_bf16<16>, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
-                           outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart);
+                           outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart, outT_f8);
     } else {
         dim3 grid((c_ext + CVT - 1) / CVT, (r_ext + CVT - 1) / CVT);
         hipLaunchKernelGGL(k_f32_to_bf16<64>, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
-                           outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart);
+                           outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart, outT_f8);
     }
     return hipGetLastError();
 }

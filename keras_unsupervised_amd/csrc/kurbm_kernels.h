@@ -130,6 +130,11 @@ struct GemmArgsB {
     // (t = k-tile * nseg + segment), so that every split-K slice gets the same mix of light and heavy tiles
     int seg_fastest;
     uint32_t inv_nseg;
+    // statistics GEMM with 0/1 data: segment 0 (v_pos^T h_pos, both operands 0/1) reads fp8 planes and runs on
+    // v_mfma_scale_f32_16x16x128_f8f6f4 -- a k-tile of the same 128 BYTES per row is 128 deep, at twice the bf16 rate and
+    // half the bytes per k.  The walk is then in UNITS of 128 k: one fp8 tile, then two 64-deep bf16 tiles of every other
+    // segment (2 nseg - 1 tiles per unit; inv_nseg inverts that count)
+    int f8pos;
     int side;             // k_gemm_pb: some test plane (prob_f32 / out_u) is requested
     int pb_max;           // k_gemm_pb: most B pieces any segment multiplies (3: x3; 1: the rounded-bf16 path)
     // filled by launch_gemm_pb: one buffer descriptor per operand (base = the lower of the two sets'
@@ -155,6 +160,8 @@ struct GemmArgsB {
     uint16_t* outT;       // bf16 [N][ldoT]  the same plane transposed; nullable
     int ldoT;
     int outT_pieces;      // 1: outT = round-to-nearest bf16; 3: exact hi / mid / lo pieces, outT_plane apart
+    int outT_f8;          // the transposed plane of a 0/1 sample leaves as fp8 bytes (e4m3: 1.0 = 0x38) instead of bf16, at the
+                          // bf16 plane's row stride (2 ldoT bytes): operand of the fp8 positive statistics (f8pos)
     int outT_neg;         // the transposed plane holds MINUS the value plane (h_neg: the negative phase of the statistics
                           // is then a plain product -- no sign handling between memory and the MFMAs)
     size_t outT_plane;
@@ -185,9 +192,11 @@ void tile_shape(int cfg, int* bm, int* bn);
 hipError_t launch_gemm_pb(int epi, const GemmArgsB& g, hipStream_t st);
 // pieces = 1: round to nearest bf16; 3: exact split x = hi + mid + lo, piece j at out + j * out_plane
 // colpart (nullable): [ceil(rows / 64)][ld_colpart] column sums of each 64-row band of `in`
+// outT_f8: the transposed plane of 0/1 data as fp8 bytes (1.0 = 0x38) at the bf16 plane's row stride (pieces = 1 only)
 hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
                               uint16_t* outT, int ldoT, int outT_rows, int pieces, size_t out_plane, size_t outT_plane,
-                              float* colpart, int ld_colpart, hipStream_t st);
+                              float* colpart, int ld_colpart, hipStream_t st, int outT_f8 = 0);
+// *flag |= 1 if some element is not exactly a bf16 value, |= 2 if some element is neither 0.0 nor 1.0
 hipError_t launch_bf16_exact_check(const float* in, int rows, int cols, int ld_in, int* flag, hipStream_t st);
 hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g, hipStream_t st);
 hipError_t launch_philox_uniform(float* out, int rows, int cols, int ld, const RngArgs& rng, hipStream_t st);

@@ -185,12 +185,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     [[maybe_unused]] const rsrc_t dB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.baseB), 0, 0xFFFFFFFF, 0x00020000);
 
     // a tile: the scalar byte offsets of its A rows and of piece 0 of its B rows
-    struct TileRef { uint32_t oa, ob, bplane; int npb; bool neg; };
+    struct TileRef { uint32_t oa, ob, bplane; int npb; bool neg, f8; };
+    constexpr bool F8 = (EPI == EPI_SLAB && PB == 3);   // the kernel that may meet fp8 tiles (g.f8pos)
     auto tile_of = [&](int t) __attribute__((always_inline)) {
         TileRef r;
         t = t < t_end ? t : t_end - 1;
         int seg, kt;
-        if (g.seg_fastest) {
+        bool f8 = false;
+        if (F8 && g.f8pos) {
+            // units of 128 k: tile 0 = segment 0 on fp8 (128 bytes of a row are 128 k), then two 64-deep tiles per other segment
+            const int per = 2 * g.nseg - 1;
+            const int unit = (int)__umulhi((uint32_t)t, g.inv_nseg), idx = t - unit * per;
+            f8 = (idx == 0);
+            seg = f8 ? 0 : 1 + ((idx - 1) >> 1);
+            kt = f8 ? unit : 2 * unit + ((idx - 1) & 1);
+        } else if (g.seg_fastest) {
             kt = g.inv_nseg ? (int)__umulhi((uint32_t)t, g.inv_nseg) : t;       // inv == 0: divisor 1
             seg = t - kt * g.nseg;
         } else {
@@ -199,9 +208,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         }
         const uint32_t code = (uint32_t)(g.seg_codes >> (5 * seg)) & 31u;
         const bool neg = (code & 16u) != 0u;
-        const uint32_t k0 = 2u * (uint32_t)(kt * BKB);
+        const uint32_t k0 = 2u * (uint32_t)(kt * BKB);   // (128 bytes per k-tile, bf16 or fp8)
         r.oa = __builtin_amdgcn_readfirstlane(2u * (code & 3u) * (uint32_t)(neg ? g.a_plane1 : g.a_plane0) + k0);
         r.neg = __builtin_amdgcn_readfirstlane((int)neg) != 0;
+        r.f8 = __builtin_amdgcn_readfirstlane((int)f8) != 0;
         r.ob = __builtin_amdgcn_readfirstlane((neg ? g.offB1 : g.offB0) + k0);
         r.bplane = __builtin_amdgcn_readfirstlane(2u * (uint32_t)(neg ? g.b_plane1 : g.b_plane0));
         r.npb = __builtin_amdgcn_readfirstlane((int)((code >> 2) & 3u));
@@ -289,9 +299,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto tile_any = [&](const int cur, int npb) __attribute__((always_inline)) {
-        if (PB >= 3 && npb == 3) one_tile(cur, std::integral_constant<int, 3>{});
-        else if (PB >= 2 && npb == 2) one_tile(cur, std::integral_constant<int, 2>{});
+    // An fp8 tile (statistics of 0/1 data, segment 0): the same 128-byte rows hold 128 k.  Lane group g = lane >> 4 of
+    // v_mfma_scale_f32_16x16x128_f8f6f4 supplies 32 bytes of its row; which 32 is free as long as A and B agree (k is a
+    // summation index), so it takes chunks g and 4 + g -- exactly the two fragment reads of a bf16 tile, and the tile is
+    // entered like any other with fa[0], fb[0] loaded.  Scale operands 0x7F = 2^0 (E8M0).
+    auto f8_tile = [&](const int cur) __attribute__((always_inline)) {
+        if constexpr (F8) {
+            typedef int i32x8 __attribute__((ext_vector_type(8)));
+            __builtin_amdgcn_sched_barrier(0);
+            frag_a(cur, 1, fa[1]);
+            frag_b(cur, 1, 0, fb[1]);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const i32x8 a = {(int)fa[0][mi].x, (int)fa[0][mi].y, (int)fa[0][mi].z, (int)fa[0][mi].w,
+                                     (int)fa[1][mi].x, (int)fa[1][mi].y, (int)fa[1][mi].z, (int)fa[1][mi].w};
+                    const i32x8 b = {(int)fb[0][ni].x, (int)fb[0][ni].y, (int)fb[0][ni].z, (int)fb[0][ni].w,
+                                     (int)fb[1][ni].x, (int)fb[1][ni].y, (int)fb[1][ni].z, (int)fb[1][ni].w};
+                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[mi][ni], 0, 0, 0, 0x7F, 0, 0x7F);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            frag_a(cur ^ 1, 0, fa[0]);
+            frag_b(cur ^ 1, 0, 0, fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto tile_any = [&](const int cur, const TileRef& r) __attribute__((always_inline)) {
+        if (F8 && r.f8) f8_tile(cur);
+        else if (PB >= 3 && r.npb == 3) one_tile(cur, std::integral_constant<int, 3>{});
+        else if (PB >= 2 && r.npb == 2) one_tile(cur, std::integral_constant<int, 2>{});
         else one_tile(cur, std::integral_constant<int, 1>{});
     };
 
@@ -405,10 +444,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         // unrolled by two: the LDS buffers alternate statically
         int i = 0;
         for (; i + 1 < nt; i += 2) {
-            tile_any(0, tile_of(t_begin + i).npb);
-            tile_any(1, tile_of(t_begin + i + 1).npb);
+            tile_any(0, tile_of(t_begin + i));
+            tile_any(1, tile_of(t_begin + i + 1));
         }
-        if (i < nt) tile_any(0, tile_of(t_begin + i).npb);
+        if (i < nt) tile_any(0, tile_of(t_begin + i));
     }
     __syncthreads();
     KURBM_STAMP(ts[2]);
@@ -602,6 +641,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = (rb + r < g.M) ? tsign * xv[mi][ni][r] : 0.f;
+                    if (g.outT_f8) {   // a 0/1 sample as four fp8 bytes (1.0 = 0x38), row stride as for bf16
+                        *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(g.outT) + (size_t)col * g.ldoT * 2 + rb) =
+                            (v[0] != 0.f ? 0x38u : 0u) | (v[1] != 0.f ? 0x3800u : 0u) | (v[2] != 0.f ? 0x380000u : 0u) |
+                            (v[3] != 0.f ? 0x38000000u : 0u);
+                        continue;
+                    }
                     uint16_t* dst = g.outT + (size_t)col * g.ldoT + rb;
                     for (int j = 0; j < np; ++j) {
                         u32x2 pk;

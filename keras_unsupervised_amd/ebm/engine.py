@@ -54,11 +54,12 @@ def device_guard(device):
 class DeviceMatrix:
     """Row-major fp32 [rows, ld] matrix on the device, ld % 4 == 0, padding zero."""
 
-    __slots__ = ("t", "rows", "cols", "ld", "bf16_exact")
+    __slots__ = ("t", "rows", "cols", "ld", "bf16_exact", "binary")
 
     def __init__(self, t, rows, cols, ld):
         self.t, self.rows, self.cols, self.ld = t, rows, cols, ld
         self.bf16_exact = None   # True / False once DeviceRBM.v_pieces() has looked (0/1 data is exact)
+        self.binary = None       # ... and whether every element is 0.0 or 1.0
 
     @classmethod
     def zeros(cls, rows, cols, device):
@@ -214,7 +215,8 @@ class DeviceRBM:
                 flag = torch.zeros(1, dtype=torch.int32, device=self.device)
                 check(self.lib.kurbm_bf16_exact(self.ctx.handle, v.ptr(), max(v.rows, 1), v.cols, v.ld, flag.data_ptr(),
                                                 self._stream()))
-                v.bf16_exact = int(flag.item()) == 0
+                bits = int(flag.item())
+                v.bf16_exact, v.binary = (bits & 1) == 0, bits == 0
         return 1 if v.bf16_exact else 3
 
     def get_weights(self):
@@ -264,6 +266,8 @@ class DeviceRBM:
         vp = self.v_pieces(v)
         if v_chain is not None and vp == 1:
             vp = 3 if mode == MODE_VISIBLE_GAUSSIAN else self.v_pieces(v_chain)
+        if vp == 1 and v.binary:
+            vp |= _lib.V_BINARY   # 0/1 data: the positive statistics run on the fp8 matrix cores (include/kurbm.h)
         return vp
 
     def make_planes(self, v, windows, mode=MODE_VISIBLE_BERNOULLI, v_chain=None):
@@ -281,6 +285,7 @@ class DeviceRBM:
     def _chain_written(self, v_chain, mode):
         if v_chain is not None:
             v_chain.bf16_exact = True if mode == MODE_VISIBLE_BERNOULLI else None
+            v_chain.binary = v_chain.bf16_exact
 
     def cd_step(self, v, rows, row_start, lr, seed, step, k=1, mode=MODE_VISIBLE_BERNOULLI, chain=0,
                 which=WHICH_ALL, apply=True, emit_delta=False, v_chain=None, row0=0, v_chain_row=0, bf16=False,
@@ -360,7 +365,7 @@ class DeviceRBM:
         """Measurement hook (bench.py): ONE launch of the x3 CD-1 sequence on the planes the previous
         complete x3 step left in the workspace; stage numbering as kurbm_cd_step_x3_stage."""
         with torch.cuda.device(self.device):
-            vp = self.v_pieces(v)
+            vp = self._x3_pieces(v, None, MODE_VISIBLE_BERNOULLI)   # (as cd_step passes it: the planes must read the same)
             mir, ws = self.mirror(3), self.workspace_bf16(rows, 1, 3, vp)
             opts = CdOpts(1, MODE_VISIBLE_BERNOULLI, float(lr), 1, None, None, int(seed), 0, int(step) & 0xFFFFFFFF, 0)
             check(self.lib.kurbm_cd_step_x3_stage(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
@@ -423,9 +428,9 @@ class DeviceRBM:
                 check(self.lib.kurbm_half_step_bf16(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), d,
                                                     x.ptr(row_start), rows, x.ld, *tail))
             if noise == NOISE_BERNOULLI and out["sample"] is not None:
-                out["sample"].bf16_exact = True        # 0/1: one bf16 piece, no need to look
+                out["sample"].bf16_exact = out["sample"].binary = True        # 0/1: one bf16 piece, no need to look
             elif noise == NOISE_GAUSSIAN and out["sample"] is not None:
-                out["sample"].bf16_exact = False
+                out["sample"].bf16_exact = out["sample"].binary = False
         return out
 
     def apply_delta(self, lr, which=WHICH_ALL, delta=None, compute=None):

@@ -444,7 +444,7 @@ def test_c_abi_from_plain_c(gpu_device, tmp_path):
                     "-lm", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 2" in r.stdout
+    assert "abi 3" in r.stdout
 
 
 def test_c_abi_error_behaviour(gpu_device):
@@ -605,7 +605,7 @@ def test_x3_epoch_call_equals_step_loop(gpu_device, resident, shape):
     planes = a.make_planes(vd, [(lo, hi - lo) for lo, hi in slices]) if resident else None
     assert (planes is not None) == resident
     if resident:
-        assert planes.uniform(0, N, bs) and planes.v_pieces == (3 if real else 1)
+        assert planes.uniform(0, N, bs) and planes.v_pieces == (3 if real else 1 | 0x10)   # (0/1 data: KURBM_V_BINARY)
     for epoch in range(2):
         assert a.cd_epoch(vd, N, bs, 0.01, 9, 5 + epoch * nsteps, k=k, compute="x3", planes=planes) == nsteps
         for i, (lo, hi) in enumerate(slices):
@@ -1182,3 +1182,46 @@ def test_x3_half_steps_tile_configs(gpu_device, ctx_option, tall, shape):
     b.cd_step(_dm(v, gpu_device), B, 0, 1e-3, 11, 0, compute="fp32")
     dW = np.abs(a.get_weights()[0] - b.get_weights()[0])
     assert np.mean(dW > 1e-6) < 1e-3 and np.all(np.isfinite(a.get_weights()[0]))
+
+
+def test_bf16_exact_flag_bits(gpu_device):
+    """kurbm_bf16_exact: bit 0 = some value is not a bf16 value, bit 1 = some value is neither 0 nor 1 (include/kurbm.h)."""
+    from keras_unsupervised_amd import _lib
+    e = _engine(*synthetic_params(24, 16, seed=1), gpu_device)
+    g = np.random.default_rng(3)
+    cases = [(synthetic_binary(130, 24, seed=2, p=0.4), 1 | _lib.V_BINARY, True),
+             ((g.integers(0, 256, (130, 24)) / 256.0).astype(np.float32), 1, False),     # grey levels: bf16-exact, not 0/1
+             (g.random((130, 24)).astype(np.float32), 3, False)]
+    for x, want_pieces, want_binary in cases:
+        d = _dm(x, gpu_device)
+        assert e._x3_pieces(d, None, O.MODE_VISIBLE_BERNOULLI) == want_pieces
+        assert bool(d.binary) == want_binary
+
+
+@pytest.mark.parametrize("cfg", [dict(B=200, nv=100, nh=80, k=1), dict(B=1024, nv=784, nh=256, k=2),
+                                 dict(B=384, nv=260, nh=520, k=1, planes=True), dict(B=256, nv=300, nh=128, k=1, gauss=True)])
+def test_x3_fp8_positive_statistics(gpu_device, ctx_option, cfg):
+    """0/1 data: v_pos^T h_pos on the fp8 matrix cores (fp8 transposed planes from the conversion kernel / the resident
+    planes and from the h_pos epilogue, 128-deep k-tiles) against the same step on bf16 planes (KURBM_X3_F8POS=0) and
+    against the oracle: the positive products are counts, exact either way, so the two differ only in the order in which
+    the negative phase's fp32 terms meet them."""
+    B, nv, nh, k = cfg["B"], cfg["nv"], cfg["nh"], cfg["k"]
+    mode = O.MODE_VISIBLE_GAUSSIAN if cfg.get("gauss") else O.MODE_VISIBLE_BERNOULLI
+    W0 = synthetic_params(nv, nh, seed=1300 + B)
+    V = synthetic_binary(B, nv, seed=1301 + B, p=0.3)
+    got = {}
+    for f8 in (1, 0):
+        ctx_option("KURBM_X3_F8POS", f8, 1)
+        e = _engine(*W0, gpu_device)
+        vd = _dm(V, gpu_device)
+        planes = e.make_planes(vd, [(0, B)], mode) if cfg.get("planes") else None
+        e.cd_step(vd, B, 0, 0.01, 9, 2, k=k, mode=mode, apply=False, emit_delta=True, compute="x3", planes=planes)
+        torch.cuda.synchronize()
+        got[f8] = _split(e.delta_buffer().cpu().numpy(), nv, nh)
+    for a, b in zip(got[1], got[0]):
+        assert np.max(np.abs(a - b)) <= 2e-6 * max(1.0, float(np.abs(b).max()))
+    assert np.array_equal(got[1][2], got[0][2]) and np.array_equal(got[1][1], got[0][1])   # the bias sums never see the planes
+    if not cfg.get("gauss") and k == 1:   # (k > 1 / Gaussian: a flip in the |u - p| < 1e-5 band changes the whole chain)
+        dW = O.cd_step_fused(*W0, V, 1.0, 9, 2)[4][0]
+        assert np.max(np.abs(got[1][0] - dW)) <= 1e-4 * max(1.0, float(np.abs(dW).max())) or \
+            np.mean(np.abs(got[1][0] - dW) > 1e-3) < 0.05   # (a band flip moves one row / column of dW by one count)
