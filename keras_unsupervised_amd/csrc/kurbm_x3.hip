@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #ifdef KURBM_STAMPS
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tu[6] = {0, 0, 0, 0, 0, 0};   // cycles per micro-step of the 3-piece tiles, summed over tiles
+    unsigned long long tk[3] = {0, 0, 0};            // cycles per KIND of tile, summed: fp8, one piece, three pieces
     KURBM_STAMP(ts[0]);
 #define KURBM_STAMP_OUT()                                                                         \
     do {                                                                                          \
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             unsigned long long* o = g.stamps + ((size_t)blockIdx.x * (NT / 64) + wave) * 16;      \
             for (int q = 0; q < 6; ++q) o[q] = ts[q];                                             \
             for (int q = 0; q < 6; ++q) o[8 + q] = tu[q];                                         \
+            o[6] = tk[0]; o[7] = tk[1]; o[14] = tk[2];                                            \
         }                                                                                         \
     } while (0)
 #else
@@ -328,10 +330,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         }
     };
     auto tile_any = [&](const int cur, const TileRef& r) __attribute__((always_inline)) {
+#ifdef KURBM_STAMPS
+        unsigned long long tk0, tk1;
+        KURBM_STAMP(tk0);
+#endif
         if (F8 && r.f8) f8_tile(cur);
         else if (PB >= 3 && r.npb == 3) one_tile(cur, std::integral_constant<int, 3>{});
         else if (PB >= 2 && r.npb == 2) one_tile(cur, std::integral_constant<int, 2>{});
         else one_tile(cur, std::integral_constant<int, 1>{});
+#ifdef KURBM_STAMPS
+        KURBM_STAMP(tk1);
+        tk[(F8 && r.f8) ? 0 : (r.npb == 3 ? 2 : 1)] += tk1 - tk0;
+#endif
     };
 
     // The Philox words of this lane's outputs do not depend on the GEMM: those of its first NI_LDS output columns are drawn

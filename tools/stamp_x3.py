@@ -38,7 +38,8 @@ def report(name, s):
         d.append(np.median((b - a)[ok]) if ok.any() else 0.0)
     end = s[:, 5].max() - t0
     print("%-10s wgs %4d | " % (name, len(s)) + "  ".join("%s %6.0f" % (n, x) for n, x in zip(NAMES[1:], d[1:]))
-          + " | tu[0..5]: " + " ".join("%6.0f" % x for x in np.median(s[:, 8:14], axis=0)))
+          + " | tu[0..5]: " + " ".join("%6.0f" % x for x in np.median(s[:, 8:14], axis=0))
+          + " | tiles fp8 / 1 piece / 3 pieces: " + " ".join("%6.0f" % np.median(s[:, q]) for q in (6, 7, 14)))
 
 
 step = lambda: eng.cd_step(V, B, 0, 1e-3 / B, 42, 0, compute="x3")
