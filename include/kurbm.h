@@ -246,10 +246,12 @@ int kurbm_half_step_bf16(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
  * v_pieces: 1 promises that every element of v_batch (and of opts->v_chain) is exactly a bf16
  * value, which 0/1 data is (check with kurbm_bf16_exact); 3 splits the batch as well.  When both
  * operands of a product are split, the three pairs of pieces below 2^-24 of the product are left out.
- * 1 | KURBM_V_BINARY additionally promises that every element of v_batch is 0.0 or 1.0 (bit 1 of kurbm_bf16_exact's flag
- * clear): the positive statistics v_pos^T h_pos are then a 0/1 x 0/1 product, which the library runs on the fp8 matrix
- * cores (exact: the operands are 0 or 1, the accumulation is fp32; twice the bf16 rate, half the bytes).  A window of
- * resident planes (kurbm_x3_convert_rows) must be made and used with the same v_pieces value.
+ * 1 | KURBM_V_BINARY additionally promises that every element of v_batch (and of opts->v_chain) is 0.0 or 1.0 (bit 1 of
+ * kurbm_bf16_exact's flag clear).  The library then keeps the data planes, like those of its own 0/1 samples, as bytes
+ * instead of bf16 (half the traffic of the A operand of a half step), and runs the positive statistics v_pos^T h_pos, a
+ * 0/1 x 0/1 product, on the fp8 matrix cores (twice the bf16 rate).  Both are exact: the operands are 0 or 1, the
+ * accumulation is fp32.  A window of resident planes (kurbm_x3_convert_rows) must be made and used with the same
+ * v_pieces value.
  * The mirror holds the pieces of W in both orientations and follows the rules of the bf16 mirror.
  */
 #define KURBM_V_BINARY 0x10

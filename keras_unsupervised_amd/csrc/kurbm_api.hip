@@ -19,12 +19,13 @@ using namespace kurbm;
 // Experiment knobs.  Every one is read from the environment ONCE, at kurbm_ctx_create, into the context (no getenv on
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
-enum { KN_LDPAD, KN_X3_F8POS, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
+enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
        KN_UNFUSED_MIRROR, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
     {"KURBM_X3_F8POS", 1},         // 0: the positive statistics of 0/1 data stay on bf16 planes
+    {"KURBM_X3_BYTES", 1},         // 0: the row-major planes of 0/1 samples / data stay bf16 (1: bytes, half the A tiles)
     {"KURBM_BF16_SPLIT", KN_AUTO}, // split-K slices of the bf16 / x3 statistics GEMM
     {"KURBM_X3_FULL", 0},          // 1: all nine piece pairs of a real x real product
     {"KURBM_X3_TALL", KN_AUTO},    // 0 / 1: never / always 256 x 64 half-step tiles
@@ -693,6 +694,7 @@ struct HalfOutB {
     int outT_pieces = 1; size_t outT_plane = 0;
     bool outT_neg = false;                                // the transposed plane is stored negated
     bool outT_f8 = false;                                 // the transposed plane of a 0/1 sample as fp8 bytes
+    bool out_bytes = false;                               // the row-major plane of a 0/1 sample as bytes (0x40 = one)
     float* out_f32 = nullptr; float* prob_f32 = nullptr; float* out_u = nullptr; int ldo32 = 0;
     float* colpart = nullptr; int ld_colpart = 0;
     float colsign = 1.f;                                  // x3: colpart = colsign * column sums of the value plane
@@ -702,7 +704,7 @@ struct HalfOutB {
 // one half step: A [rows][lda] bf16 in a_pieces pieces (k padded), weights from the mirror
 static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const Mirror& m, const uint16_t* A, int lda,
                        int a_pieces, size_t a_plane, int rows, int act, int noise, const RngArgs* rng, const HalfOutB& o,
-                       hipStream_t st) {
+                       hipStream_t st, bool a_bytes = false) {
     GemmArgsB g;
     memset(&g, 0, sizeof g);
     const bool vh = (layout == LAYOUT_VH);
@@ -713,6 +715,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip); rounded bf16: against its one piece
         g.nseg = pb_codes(ctx, a_pieces, m.pieces, 0u, &g.seg_codes, 0);
         g.pb_max = m.pieces;
+        g.a_bytes = a_bytes ? 1 : 0;   // (a byte plane of 0/1 values: one piece, lda bytes between its rows)
         g.cfg = 0;
         // 2: 256 x 64 tiles (fewer bytes per k-tile).  Whole 256-row tiles only: the bias partial rows are laid out
         // per 64 rows, two per 128-row tile, and an even number of those is what both tilings agree on
@@ -729,7 +732,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.act = act; g.noise = noise;
         if (rng) g.rng = *rng;
         g.out = o.out; g.ldo = o.ldo; g.ldo_cols = o.out ? o.ldo : g.N;
-        g.out_pieces = o.out_pieces; g.out_plane = o.out_plane;
+        g.out_pieces = o.out_pieces; g.out_plane = o.out_plane; g.out_bytes = o.out_bytes ? 1 : 0;
         g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
         g.outT_neg = o.outT_neg ? 1 : 0; g.outT_f8 = o.outT_f8 ? 1 : 0;
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
@@ -827,6 +830,10 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     const int vn_pieces = (pieces == 3 && gauss) ? 3 : 1;
     // 0/1 data on the x3 path: v_pos^T and h_pos^T leave as fp8 planes and their product runs on the fp8 matrix cores
     const bool f8pos = v_binary && pieces == 3 && ctx->knob[KN_X3_F8POS] != 0;
+    // ... and every row-major plane of 0/1 values is a BYTE plane (half the A tile of the half step that reads it): the
+    // hidden samples always, v_pos / the persistent chain for 0/1 data, the negative visibles in Bernoulli mode
+    const bool byt = pieces == 3 && ctx->knob[KN_X3_BYTES] != 0;
+    const bool hbytes = byt, vbytes = byt && v_binary, nbytes = byt && !gauss;
     int e;
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
@@ -841,22 +848,23 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         w.vb = vp.vb; w.vbT = vp.vbT; part_v_pos = vp.part_v;
     } else if (KURBM_STAGE(0))
         HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Lv, w.Kb, w.vbT, w.Lb, p->n_vis, v_pieces, w.planeV,
-                                   w.planeVT, w.part_v, w.ldv32, st, f8pos ? 1 : 0));
+                                   w.planeVT, w.part_v, w.ldv32, st, f8pos ? 1 : 0, vbytes ? 1 : 0));
     // h_pos ~ p(h | v_pos)                                          rbm.py:120
     RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
     if (KURBM_STAGE(1)) {
         HalfOutB ho;
-        ho.out = w.hb; ho.ldo = w.Lh; ho.outT = w.hbT; ho.ldoT = w.Lb; ho.outT_f8 = f8pos;
+        ho.out = w.hb; ho.ldo = w.Lh; ho.out_bytes = hbytes; ho.outT = w.hbT; ho.ldoT = w.Lb; ho.outT_f8 = f8pos;
         ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.colsign = 1.f;
-        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st, vbytes))) return e;
     }
     const uint16_t* h_cur = w.hb;
     if (o->v_chain && KURBM_STAGE(1)) {   // persistent chain: negative phase starts from the stored fantasy particles
-        HIP_TRY(launch_f32_to_bf16(o->v_chain, rows, p->n_vis, ldv, w.cb, w.Lv, w.Kb, nullptr, 0, 0, v_pieces, w.planeV, 0, nullptr, 0, st));
+        HIP_TRY(launch_f32_to_bf16(o->v_chain, rows, p->n_vis, ldv, w.cb, w.Lv, w.Kb, nullptr, 0, 0, v_pieces, w.planeV, 0, nullptr, 0, st,
+                                   0, vbytes ? 1 : 0));
         r = make_rng(o->seed, o->row0, base + 32u, o->step);
         HalfOutB ho;
-        ho.out = w.h2b; ho.ldo = w.Lh;
-        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.cb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
+        ho.out = w.h2b; ho.ldo = w.Lh; ho.out_bytes = hbytes;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.cb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st, vbytes))) return e;
         h_cur = w.h2b;
     }
     int gm_v = ceil_div(rows, 128), gm_h = gm_v;   // row tiles of the half steps (bias partial rows)
@@ -865,7 +873,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         r = make_rng(o->seed, o->row0, base + 2u * t - 1u, o->step);      // v_t ~ p(v | h_{t-1})   rbm.py:121-123
         if (KURBM_STAGE(2)) {
             HalfOutB ho;
-            ho.out = w.v2b; ho.ldo = w.Lv; ho.out_pieces = vn_pieces; ho.out_plane = w.planeV;
+            ho.out = w.v2b; ho.ldo = w.Lv; ho.out_pieces = vn_pieces; ho.out_plane = w.planeV; ho.out_bytes = nbytes;
             if (last) {
                 ho.outT = w.v2bT; ho.ldoT = w.Lb; ho.outT_pieces = vn_pieces; ho.outT_plane = w.planeVT;
                 ho.out_f32 = o->v_chain; ho.ldo32 = ldv;
@@ -874,13 +882,13 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             // -sum(v_neg) below the bands of +sum(v_pos); nothing for the inner steps of CD-k
             ho.colpart = last ? w.part_v + (size_t)gp_v * w.ldv32 : nullptr; ho.ld_colpart = w.ldv32;
             ho.colsign = -1.f;
-            if ((e = half_step_b(ctx, LAYOUT_HV, p, m, h_cur, w.Lh, 1, 0, rows, act_v, noise_v, &r, ho, st))) return e;
+            if ((e = half_step_b(ctx, LAYOUT_HV, p, m, h_cur, w.Lh, 1, 0, rows, act_v, noise_v, &r, ho, st, hbytes))) return e;
         }
         if (!last && KURBM_STAGE(2)) {
             r = make_rng(o->seed, o->row0, base + 2u * t, o->step);
             HalfOutB ho;
-            ho.out = w.h2b; ho.ldo = w.Lh;
-            if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st))) return e;
+            ho.out = w.h2b; ho.ldo = w.Lh; ho.out_bytes = hbytes;
+            if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st, nbytes))) return e;
             h_cur = w.h2b;
         }
     }
@@ -891,7 +899,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         ho.outT = w.hnT; ho.ldoT = w.Lb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT; ho.outT_neg = true;
         ho.colpart = w.part_h + (size_t)2 * ceil_div(rows, 128) * w.ldh32; ho.ld_colpart = w.ldh32; ho.colsign = -1.f;
         ho.grid_m_out = &gm_h;
-        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st))) return e;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st, nbytes))) return e;
     }
 
     // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
@@ -1210,6 +1218,7 @@ int kurbm_x3_convert_rows(kurbm_ctx* ctx, const float* v, int rows, int ldv, int
     if (!ctx) return fail(KURBM_ERR_ARG, "ctx is null");
     // 0/1 data: the transposed plane (operand of the positive statistics only) as fp8, as the steps will read it
     const bool f8 = (v_pieces == (1 | KURBM_V_BINARY)) && ctx->knob[KN_X3_F8POS] != 0;
+    const bool vbytes = (v_pieces == (1 | KURBM_V_BINARY)) && ctx->knob[KN_X3_BYTES] != 0;   // ... and the row-major one as bytes
     if (v_pieces == (1 | KURBM_V_BINARY)) v_pieces = 1;
     if (rows <= 0 || n_vis <= 0 || (v_pieces != 1 && v_pieces != 3)) return fail(KURBM_ERR_ARG, "bad shape / v_pieces");
     if (bad_matrix(v, ldv, n_vis)) return fail(KURBM_ERR_ARG, "v: null, misaligned, ld %% 4 != 0 or ld < n_vis");
@@ -1218,7 +1227,7 @@ int kurbm_x3_convert_rows(kurbm_ctx* ctx, const float* v, int rows, int ldv, int
     if (vp.bytes > planes_bytes) return fail(KURBM_ERR_WORKSPACE, "planes too small: need %zu bytes, got %zu", vp.bytes, planes_bytes);
     const int Kb = round_up(rows, 128), Lv = ld_pad(ctx, round_up(n_vis, 128)), Lb = ld_pad(ctx, Kb);
     HIP_TRY(launch_f32_to_bf16(v, rows, n_vis, ldv, vp.vb, Lv, Kb, vp.vbT, Lb, n_vis, v_pieces, (size_t)Kb * Lv, (size_t)n_vis * Lb,
-                               vp.part_v, round_up(n_vis, 4), static_cast<hipStream_t>(stream), f8 ? 1 : 0));
+                               vp.part_v, round_up(n_vis, 4), static_cast<hipStream_t>(stream), f8 ? 1 : 0, vbytes ? 1 : 0));
     return KURBM_OK;
 }
 

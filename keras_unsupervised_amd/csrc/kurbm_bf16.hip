@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
                                                      uint16_t* __restrict__ out, int ldo, int out_rows,
                                                      uint16_t* __restrict__ outT, int ldoT, int outT_rows,
                                                      int pieces, size_t out_plane, size_t outT_plane,
-                                                     float* __restrict__ colpart, int ld_colpart, int outT_f8) {
+                                                     float* __restrict__ colpart, int ld_colpart, int outT_f8, int out_bytes) {
     __shared__ float tile[TR][CVT + 1];
     const int t = threadIdx.x;
     const int q4 = (t & 15) * 4, rq = t >> 4;           // 16 lanes x 4 elements across, 16 rows per pass
@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
         }
         tile[rq + 16 * j][q4 + 0] = v.x; tile[rq + 16 * j][q4 + 1] = v.y;
         tile[rq + 16 * j][q4 + 2] = v.z; tile[rq + 16 * j][q4 + 3] = v.w;
-        if (out && r < out_rows && c < ldo) store3(out + (size_t)r * ldo + c, out_plane, v.x, v.y, v.z, v.w);   // ldo % 8 == 0
+        if (out && out_bytes) {   // 0/1 data as a byte plane (0x40 = one), ldo bytes between its rows
+            if (r < out_rows && c < ldo)
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(out) + (size_t)r * ldo + c) =
+                    (v.x != 0.f ? 0x40u : 0u) | (v.y != 0.f ? 0x4000u : 0u) | (v.z != 0.f ? 0x400000u : 0u) | (v.w != 0.f ? 0x40000000u : 0u);
+        } else if (out && r < out_rows && c < ldo) store3(out + (size_t)r * ldo + c, out_plane, v.x, v.y, v.z, v.w);   // ldo % 8 == 0
     }
     if (!outT && !colpart) return;
     __syncthreads();
@@ -250,8 +254,8 @@ __global__ __launch_bounds__(256) void k_bf16_exact_check(const float* __restric
 // ------------------------------------------------------------------------------------
 hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
                               uint16_t* outT, int ldoT, int outT_rows, int pieces, size_t out_plane, size_t outT_plane,
-                              float* colpart, int ld_colpart, hipStream_t st, int outT_f8) {
-    if (outT_f8 && pieces != 1) return hipErrorInvalidValue;
+                              float* colpart, int ld_colpart, hipStream_t st, int outT_f8, int out_bytes) {
+    if ((outT_f8 || out_bytes) && pieces != 1) return hipErrorInvalidValue;
     // cover the padded extents of whichever mirrors are requested
     int r_ext = rows, c_ext = cols;
     if (out) { if (out_rows > r_ext) r_ext = out_rows; if (ldo > c_ext) c_ext = ldo; }
@@ -261,11 +265,11 @@ hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, ui
     if (small) {
         dim3 grid((c_ext + CVT - 1) / CVT, (r_ext + 15) / 16);
         hipLaunchKernelGGL(k_f32_to_bf16<16>, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
-                           outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart, outT_f8);
+                           outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart, outT_f8, out_bytes);
     } else {
         dim3 grid((c_ext + CVT - 1) / CVT, (r_ext + CVT - 1) / CVT);
         hipLaunchKernelGGL(k_f32_to_bf16<64>, grid, dim3(256), 0, st, in, rows, cols, ld_in, out, ldo, out_rows, outT, ldoT,
-                           outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart, outT_f8);
+                           outT_rows, pieces, out_plane, outT_plane, colpart, ld_colpart, outT_f8, out_bytes);
     }
     return hipGetLastError();
 }

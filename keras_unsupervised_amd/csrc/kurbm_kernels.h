@@ -155,6 +155,8 @@ struct GemmArgsB {
     uint16_t* out;        // bf16 [M][ldo]   value plane (sample, or prob when noise = NONE); nullable
     int ldo;
     int out_pieces;       // k_gemm_pb: 1 = the plane is 0/1 (one exact piece); 3 = real-valued, hi / mid / lo, out_plane apart
+    int out_bytes;        // the row-major plane of a 0/1 sample leaves as BYTES (0x40 = one), ldo bytes between its rows
+    int a_bytes;          // the A operand is such a byte plane (lda bytes between its rows; one segment): k_gemm_pb<..., AB>
     size_t out_plane;
     int ldo_cols;         // columns the row planes cover: ldo when `out` is set (pads are zeroed), else N
     uint16_t* outT;       // bf16 [N][ldoT]  the same plane transposed; nullable
@@ -192,10 +194,11 @@ void tile_shape(int cfg, int* bm, int* bn);
 hipError_t launch_gemm_pb(int epi, const GemmArgsB& g, hipStream_t st);
 // pieces = 1: round to nearest bf16; 3: exact split x = hi + mid + lo, piece j at out + j * out_plane
 // colpart (nullable): [ceil(rows / 64)][ld_colpart] column sums of each 64-row band of `in`
-// outT_f8: the transposed plane of 0/1 data as fp8 bytes (1.0 = 0x38) at the bf16 plane's row stride (pieces = 1 only)
+// 0/1 data (pieces = 1 only).  outT_f8: the transposed plane as fp8 bytes (1.0 = 0x38) at the bf16 plane's row stride;
+// out_bytes: the row-major plane as bytes (0x40 = one), ldo BYTES between its rows
 hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ldo, int out_rows,
                               uint16_t* outT, int ldoT, int outT_rows, int pieces, size_t out_plane, size_t outT_plane,
-                              float* colpart, int ld_colpart, hipStream_t st, int outT_f8 = 0);
+                              float* colpart, int ld_colpart, hipStream_t st, int outT_f8 = 0, int out_bytes = 0);
 // *flag |= 1 if some element is not exactly a bf16 value, |= 2 if some element is neither 0.0 nor 1.0
 hipError_t launch_bf16_exact_check(const float* in, int rows, int cols, int ld_in, int* flag, hipStream_t st);
 hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g, hipStream_t st);

@@ -68,7 +68,13 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // and LDS -- and the MFMA waves only read fragments, issue MFMAs and meet the loaders at the tile's barrier.  A stall of a
 // staging instruction then never sits in the instruction stream of a wave that has MFMAs to issue: with staging in the
 // MFMA waves the k loop took twice the time of its MFMAs alone (round 1), wherever in the tile the staging was put.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int PB, int EPI, int NOISE>
+//
+// AB: the A operand is a BYTE plane -- a 0/1 sample or 0/1 data, one byte per element, 0x40 for one: behind a zero low byte
+// that is the bf16 value 2.0, and the epilogue halves the sum (exact).  Half the bytes of the A operand from L2 and through
+// LDS (with DMA staging a tile's time follows the 128-byte lines it takes in).  So that the lines stay whole, an A row in
+// LDS is 128 BYTES = 128 k, an A BLOCK that serves two 64-deep k-tiles: two block buffers beside the two B stages, half a
+// block requested per tile.  The MFMA waves read 8-byte fragments and expand them with four v_perm_b32 per k-step.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int PB, int EPI, int NOISE, bool AB = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES_N + 256) / 256) void k_gemm_pb(GemmArgsB g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;          // threads of the MFMA waves (and of every epilogue loop)
     constexpr int NTS = 256;                            // threads of the loader waves
@@ -85,14 +91,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     static_assert(KS == 2, "fragment buffers alternate with the k-step");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;
-    constexpr int A_BYTES = BM * ROWB, B1_BYTES = BN * ROWB, B_BYTES = PB * B1_BYTES;
-    constexpr int STAGE = A_BYTES + B_BYTES;
+    static_assert(!AB || EPI == EPI_HALFSTEP, "byte A tiles: half steps");
+    constexpr int A_BYTES = BM * ROWB, B1_BYTES = BN * ROWB, B_BYTES = PB * B1_BYTES;   // (AB: A_BYTES is a BLOCK, 128 k deep)
+    // LDS: two stages [A tile | B pieces]; AB: two A blocks, then two stages of B pieces
+    constexpr int STAGE = AB ? B_BYTES : A_BYTES + B_BYTES;
+    constexpr int B_OFF = AB ? 2 * A_BYTES : A_BYTES;
     constexpr int NA = BM * CPR / NTS, NB1 = BN * CPR / NTS;   // 1-KiB pieces per loader wave: A tile, ONE piece of B
-    static_assert((BM * CPR) % NTS == 0 && (BN * CPR) % NTS == 0, "whole chunks per lane");
+    static_assert((BM * CPR) % NTS == 0 && (BN * CPR) % NTS == 0 && NA % 2 == 0, "whole pieces per loader wave");
     constexpr int PROW16 = 2 * BN + 16;   // bf16 patch row (bytes)
     constexpr int PROW32 = 4 * BN + 16;   // fp32 patch row (bytes)
     constexpr int PATCH_BYTES = (EPI == EPI_SOFTPLUS) ? WAVES_N * BM * 4 : BM * (EPI == EPI_SLAB ? PROW32 : PROW16);
-    constexpr int SMEM_BYTES = (2 * STAGE > PATCH_BYTES) ? 2 * STAGE : PATCH_BYTES;
+    constexpr int STAGES_BYTES = 2 * (A_BYTES + B_BYTES);
+    constexpr int SMEM_BYTES = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
     // the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
     // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
     constexpr int NI_LDS = (EPI == EPI_HALFSTEP && NOISE == NOISE_BERNOULLI) ? 1 : 0;
@@ -115,15 +125,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #define KURBM_STAMP_OUT()                                                                         \
     do {                                                                                          \
         KURBM_STAMP(ts[5]);                                                                       \
-        if (g.stamps && lane == 0) {                                                              \
+        if (g.stamps && lane == 0 && wave != 7) {                                                 \
             unsigned long long* o = g.stamps + ((size_t)blockIdx.x * (NT / 64) + wave) * 16;      \
             for (int q = 0; q < 6; ++q) o[q] = ts[q];                                             \
             for (int q = 0; q < 6; ++q) o[8 + q] = tu[q];                                         \
             o[6] = tk[0]; o[7] = tk[1]; o[14] = tk[2];                                            \
         }                                                                                         \
     } while (0)
+    // the first loader wave's loop, summed over its tiles: issue of a tile's DMA / wait for it to land / wait at the barrier;
+    // written where MFMA wave 7 would write (that wave's stamps are dropped)
+    unsigned long long tl[4] = {0, 0, 0, 0}, tls[3] = {0, 0, 0};
+#define KURBM_LSTAMP(q)                                                   \
+    do {                                                                  \
+        KURBM_STAMP(tl[q]);                                               \
+        if ((q) >= 1) tls[(q) - 1] += tl[q] - tl[(q) - 1];                \
+    } while (0)
+#define KURBM_LSTAMP_OUT()                                                                        \
+    do {                                                                                          \
+        if (g.stamps && lane == 0 && wave == NT / 64) {                                           \
+            unsigned long long* o = g.stamps + ((size_t)blockIdx.x * (NT / 64) + 7) * 16;         \
+            o[0] = 1; o[1] = tls[0]; o[2] = tls[1]; o[3] = tls[2];                                \
+        }                                                                                         \
+    } while (0)
 #else
 #define KURBM_STAMP_OUT() do { } while (0)
+#define KURBM_LSTAMP(q) do { } while (0)
+#define KURBM_LSTAMP_OUT() do { } while (0)
 #endif
 
     const int nwg = gridDim.x;
@@ -170,7 +197,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     for (int it = 0; it < NA; ++it) {
         const int q = it * NTS + stid, row = q / CPR, ch = q % CPR;
         const int x = (m0 + row < g.M) ? m0 + row : 0;
-        goffA[it] = 2u * (unsigned)(x * g.lda + 8 * (ch ^ ((row >> 1) & 7)));
+        // (a byte plane has lda BYTES between its rows; its 128-byte row piece is 128 k)
+        goffA[it] = AB ? (unsigned)(x * g.lda + 16 * (ch ^ ((row >> 1) & 7))) : 2u * (unsigned)(x * g.lda + 8 * (ch ^ ((row >> 1) & 7)));
     }
 #pragma unroll
     for (int it = 0; it < NB1; ++it) {
@@ -211,7 +239,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         const uint32_t code = (uint32_t)(g.seg_codes >> (5 * seg)) & 31u;
         const bool neg = (code & 16u) != 0u;
         const uint32_t k0 = 2u * (uint32_t)(kt * BKB);   // (128 bytes per k-tile, bf16 or fp8)
-        r.oa = __builtin_amdgcn_readfirstlane(2u * (code & 3u) * (uint32_t)(neg ? g.a_plane1 : g.a_plane0) + k0);
+        r.oa = __builtin_amdgcn_readfirstlane(2u * (code & 3u) * (uint32_t)(neg ? g.a_plane1 : g.a_plane0) + k0);   // (AB: unused)
         r.neg = __builtin_amdgcn_readfirstlane((int)neg) != 0;
         r.f8 = __builtin_amdgcn_readfirstlane((int)f8) != 0;
         r.ob = __builtin_amdgcn_readfirstlane((neg ? g.offB1 : g.offB0) + k0);
@@ -226,26 +254,53 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 fa[2][TM], fb[3][TN];   // fragment buffers: A by k-step; B by micro-step (three: read two steps ahead)
+    typedef std::conditional_t<AB, u32x2, u32x4> afrag;   // (a byte fragment is 8 bytes; it is expanded where it is used)
+    afrag fa[2][TM];
+    u32x4 fb[3][TN];   // fragment buffers: A by k-step; B by micro-step (three: read two steps ahead)
     // fragment rows are l15 + a multiple of 16, so their swizzle key is (l15 >> 1) & 7
     const int swz = (l15 >> 1) & 7;
-    auto frag_a = [&](int buf, int ks, u32x4 (&f)[TM]) __attribute__((always_inline)) {
-        const unsigned char* c = smem + buf * STAGE + (wm * WM + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
+    // AB: `ablk` = the block buffer (0 / 1) of the tile pair in work; tile `buf` (= its parity) is half `buf` of the block's k
+    int ablk = 0;
+    auto frag_a = [&](int buf, int ks, afrag (&f)[TM], int blk_step = 0) __attribute__((always_inline)) {
+        if constexpr (AB) {   // k = 64 buf + 32 ks + 8 slot ...: chunk 4 buf + 2 ks + slot / 2 of the 128-byte row, its half slot % 2
+            const unsigned char* c = smem + ((ablk + blk_step) & 1) * A_BYTES + (wm * WM + l15) * ROWB +
+                                     16 * ((4 * buf + 2 * ks + (slot >> 1)) ^ swz) + 8 * (slot & 1);
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
+            for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x2*>(c + mi * 16 * ROWB);
+        } else {
+            const unsigned char* c = smem + buf * STAGE + (wm * WM + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
+        }
     };
     auto frag_b = [&](int buf, int ks, int p, u32x4 (&f)[TN]) __attribute__((always_inline)) {
-        const unsigned char* c = smem + buf * STAGE + A_BYTES + p * B1_BYTES + (wn * WN + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
+        const unsigned char* c = smem + buf * STAGE + B_OFF + p * B1_BYTES + (wn * WN + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) f[ni] = *reinterpret_cast<const u32x4*>(c + ni * 16 * ROWB);
     };
-    auto mfmas = [&](const u32x4 (&a)[TM], const u32x4 (&b)[TN]) __attribute__((always_inline)) {
+    // AB: the fragments of the k-step in use, expanded (byte b -> bf16 b << 8: v_perm_b32 picks {byte, 0} pairs) once per
+    // k-step, behind the last MFMAs of the step before (so the permutes run while the matrix pipe drains those); raw
+    // double buffer + this = the registers of the bf16 fragments
+    [[maybe_unused]] u32x4 fx[AB ? TM : 1];
+    auto expand_a = [&](const afrag (&a)[TM]) __attribute__((always_inline)) {
+        if constexpr (AB) {
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+            for (int mi = 0; mi < TM; ++mi)
+                fx[mi] = u32x4{__builtin_amdgcn_perm(0u, a[mi].x, 0x010C000Cu), __builtin_amdgcn_perm(0u, a[mi].x, 0x030C020Cu),
+                               __builtin_amdgcn_perm(0u, a[mi].y, 0x010C000Cu), __builtin_amdgcn_perm(0u, a[mi].y, 0x030C020Cu)};
+        }
+    };
+    auto mfmas = [&](const afrag (&a)[TM], const u32x4 (&b)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            u32x4 am;
+            if constexpr (AB) am = fx[mi];
+            else am = a[mi];
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+                    __builtin_bit_cast(bf16x8, am), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+        }
     };
 
     // One tile with NPB pieces = KS * NPB micro-steps (k-step ks = u / NPB, piece p = u % NPB).  Every micro-step's
@@ -270,13 +325,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 if (u == 1) { frag_a(cur, 1, fa[1]); frag_b(cur, 1, 0, fb[0]); }
                 if (u == 2) frag_b(cur, 1, 1, fb[1]);
                 if (u == 3) frag_b(cur, 1, 2, fb[2]);
-                if (u == NU - 1) {
+#ifndef KURBM_BARRIER_AT
+#define KURBM_BARRIER_AT 5
+#endif
+                static_assert(KURBM_BARRIER_AT == 3 || KURBM_BARRIER_AT == 5, "the tile's barrier: behind micro-step 3, or in front of 5");
+                // The tile's ONLY barrier sits behind micro-step 3, the last one that reads this tile (so the loaders may
+                // refill its stage), not at the tile's end: the next tile's first fragments are then read under the MFMAs
+                // of micro-steps 4 and 5 instead of in front of an idle matrix pipe
+                if (KURBM_BARRIER_AT == 5 && u == NU - 1) {
                     __syncthreads();
                     __builtin_amdgcn_sched_barrier(0);
-                    frag_a(cur ^ 1, 0, fa[0]);
+                }
+#ifndef KURBM_NEXT_READ_AT
+#define KURBM_NEXT_READ_AT (KURBM_BARRIER_AT == 5 ? 5 : KURBM_BARRIER_AT + 1)
+#endif
+                if (u == KURBM_NEXT_READ_AT) {
+                    frag_a(cur ^ 1, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
                     frag_b(cur ^ 1, 0, 0, fb[0]);
                 }
                 mfmas(fa[ks & 1], fb[u % 3]);
+                if (KURBM_BARRIER_AT == 3 && u == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (AB && (u + 1) % NPB == 0) {   // the NEXT k-step's, behind this step's MFMAs (same registers: not among them)
+                    __builtin_amdgcn_sched_barrier(0);
+                    expand_a(fa[((u + 1) / NPB) & 1]);
+                }
 #ifdef KURBM_STAMPS
                 KURBM_STAMP(tq[u + 1]);
                 tu[u] += tq[u + 1] - tq[u];
@@ -290,10 +366,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             } else {
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
-                frag_a(cur ^ 1, 0, fa[0]);
+                frag_a(cur ^ 1, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
                 frag_b(cur ^ 1, 0, 0, fb[0]);
             }
             mfmas(fa[ks & 1], fb[u & 1]);
+            if (AB && (u + 1) % NPB == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                expand_a(fa[((u + 1) / NPB) & 1]);
+            }
 #ifdef KURBM_STAMPS
             KURBM_STAMP(tq[u + 1]);
             if (NPB == 3) tu[u] += tq[u + 1] - tq[u];
@@ -306,7 +386,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // summation index), so it takes chunks g and 4 + g -- exactly the two fragment reads of a bf16 tile, and the tile is
     // entered like any other with fa[0], fb[0] loaded.  Scale operands 0x7F = 2^0 (E8M0).
     auto f8_tile = [&](const int cur) __attribute__((always_inline)) {
-        if constexpr (F8) {
+        if constexpr (F8 && !AB) {
             typedef int i32x8 __attribute__((ext_vector_type(8)));
             __builtin_amdgcn_sched_barrier(0);
             frag_a(cur, 1, fa[1]);
@@ -324,7 +404,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
-            frag_a(cur ^ 1, 0, fa[0]);
+            frag_a(cur ^ 1, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
             frag_b(cur ^ 1, 0, 0, fb[0]);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -368,41 +448,78 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         biasv[ni] = (EPI == EPI_HALFSTEP && c < g.N) ? g.bias[c] : 0.f;
     }
     if (loader) {
+#ifdef KURBM_LOADER_PRIO
+        __builtin_amdgcn_s_setprio(KURBM_LOADER_PRIO);
+#endif
         // ---- loader waves: a loop of their own; one barrier per tile, like the MFMA waves.  `buffer_load_dwordx4 ... lds`,
         // one 1-KiB piece (8 rows of a tile) per wave instruction, straight into the stage that the barrier before has
         // freed; the wait for a tile's pieces and then the tile's barrier make them visible to the MFMA waves
         // (cdna_hip_programming.md 5, "Read a staged buffer one phase AFTER the wait that retires it").
         if (nt > 0) {
-            auto dma_tile = [&](int buf, const TileRef& r) __attribute__((always_inline)) {
+            // part: bit 0 = the A tile (AB: pieces [a_lo, a_hi) of A block `ablk_`, whose k offset is r.oa), bit 1 = the B pieces
+            auto dma_part = [&](int buf, const TileRef& r, int part, int ablk_ = 0, int a_lo = 0, int a_hi = 1 << 20) __attribute__((always_inline)) {
 #if defined(KURBM_ABLATE) && (KURBM_ABLATE & 1)
                 return;   // timing-only build: no global loads
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass drops a kernel's launch stub over the LDS address-space cast)
                 typedef __attribute__((address_space(3))) void* lds_ptr;
                 const int lw = wave - NT / 64;
-                unsigned char* a = smem + buf * STAGE + lw * 8 * ROWB;
-                if (r.neg) {   // (wave-uniform)
+                if (part & 1) {
+                    unsigned char* a = smem + (AB ? ablk_ * A_BYTES : buf * STAGE) + lw * 8 * ROWB;   // piece it * 4 + lw
+                    if (r.neg) {   // (wave-uniform)
 #pragma unroll
-                    for (int it = 0; it < NA; ++it)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(dA1, (lds_ptr)(a + it * 32 * ROWB), 16, goffA[it], r.oa, 0, 0);
-                } else {
+                        for (int it = 0; it < NA; ++it)
+                            if (it >= a_lo && it < a_hi)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(dA1, (lds_ptr)(a + it * 32 * ROWB), 16, goffA[it], r.oa, 0, 0);
+                    } else {
 #pragma unroll
-                    for (int it = 0; it < NA; ++it)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(dA0, (lds_ptr)(a + it * 32 * ROWB), 16, goffA[it], r.oa, 0, 0);
+                        for (int it = 0; it < NA; ++it)
+                            if (it >= a_lo && it < a_hi)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(dA0, (lds_ptr)(a + it * 32 * ROWB), 16, goffA[it], r.oa, 0, 0);
+                    }
                 }
+                if (part & 2) {
+                    unsigned char* b = smem + buf * STAGE + B_OFF + lw * 8 * ROWB;
 #pragma unroll
-                for (int p = 0; p < PB; ++p) {
-                    if (p >= r.npb) break;   // (wave-uniform)
-                    const uint32_t so = r.ob + (uint32_t)p * r.bplane;
+                    for (int p = 0; p < PB; ++p) {
+                        if (p >= r.npb) break;   // (wave-uniform)
+                        const uint32_t so = r.ob + (uint32_t)p * r.bplane;
 #pragma unroll
-                    for (int it = 0; it < NB1; ++it)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(dB, (lds_ptr)(a + A_BYTES + p * B1_BYTES + it * 32 * ROWB), 16, goffB[it], so, 0, 0);
+                        for (int it = 0; it < NB1; ++it)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(dB, (lds_ptr)(b + p * B1_BYTES + it * 32 * ROWB), 16, goffB[it], so, 0, 0);
+                    }
                 }
 #endif
             };
+            auto dma_tile = [&](int buf, const TileRef& r) __attribute__((always_inline)) { dma_part(buf, r, 3); };
             // raw barriers and explicit waits: `s_waitcnt` with expcnt / lgkmcnt not waited for, vmcnt in bits 3:0 and 15:14
             constexpr int VM0 = 0x0F70;
             auto vm = [](int n) constexpr { return VM0 | (n & 15) | ((n >> 4) << 14); };
+            if constexpr (AB) {
+                // A block j (128 k of bytes) serves tiles 2 j and 2 j + 1; while tile i is multiplied, the B pieces of tile
+                // i + 1 and HALF of block i / 2 + 1 are requested (its buffer was freed by tile 2 (i / 2) - 1)
+                TileRef ra = tile_of(t_begin);
+                ra.neg = false; ra.oa = 0u;
+                dma_part(0, ra, 3, 0);
+                __builtin_amdgcn_s_waitcnt(VM0);
+                __builtin_amdgcn_s_barrier();
+                for (int i = 0; i < nt; ++i) {
+                    KURBM_LSTAMP(0);
+                    if (i + 1 < nt) dma_part((i + 1) & 1, tile_of(t_begin + i + 1), 2);
+                    const int jb = (i >> 1) + 1;
+                    if (2 * jb < nt) {
+                        ra.oa = __builtin_amdgcn_readfirstlane(128u * (uint32_t)((t_begin >> 1) + jb));
+                        if (i & 1) dma_part(0, ra, 1, jb & 1, NA / 2, NA);
+                        else dma_part(0, ra, 1, jb & 1, 0, NA / 2);
+                    }
+                    KURBM_LSTAMP(1);
+                    __builtin_amdgcn_s_waitcnt(VM0);
+                    KURBM_LSTAMP(2);
+                    __builtin_amdgcn_s_barrier();
+                    KURBM_LSTAMP(3);
+                }
+                KURBM_LSTAMP_OUT();
+            } else {
             // both stages are free at the start: tiles 0 and 1 are requested back to back, and the first barrier waits for
             // tile 0's pieces only (a counted vmcnt leaves tile 1's in flight)
             dma_tile(0, tile_of(t_begin));
@@ -417,9 +534,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             }
             __builtin_amdgcn_s_barrier();
             for (int i = 0; i < nt; ++i) {
+                KURBM_LSTAMP(0);
                 if (i >= 1 && i + 1 < nt) dma_tile((i + 1) & 1, tile_of(t_begin + i + 1));
+                KURBM_LSTAMP(1);
                 __builtin_amdgcn_s_waitcnt(VM0);
+                KURBM_LSTAMP(2);
                 __builtin_amdgcn_s_barrier();
+                KURBM_LSTAMP(3);
+            }
+            KURBM_LSTAMP_OUT();
             }
         }
         __syncthreads();
@@ -445,17 +568,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 }
         }
     }
-    __builtin_amdgcn_s_setprio(2);   // the MFMA waves go first wherever a loader wave competes for issue
+#ifndef KURBM_MFMA_PRIO
+#define KURBM_MFMA_PRIO 2
+#endif
+    __builtin_amdgcn_s_setprio(KURBM_MFMA_PRIO);   // the MFMA waves go first wherever a loader wave competes for issue
     if (nt > 0) {
         __syncthreads();
         frag_a(0, 0, fa[0]);
         frag_b(0, 0, 0, fb[0]);
+        expand_a(fa[0]);
         KURBM_STAMP(ts[1]);
         // unrolled by two: the LDS buffers alternate statically
         int i = 0;
         for (; i + 1 < nt; i += 2) {
             tile_any(0, tile_of(t_begin + i));
             tile_any(1, tile_of(t_begin + i + 1));
+            ablk ^= 1;
         }
         if (i < nt) tile_any(0, tile_of(t_begin + i));
     }
@@ -535,7 +663,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     float xv[TM][TN][4];   // the value plane: the sample, or the probability when nothing is drawn
     int colb = n0 + wn * WN + l15;
     asm volatile("" : "+v"(colb));   // opaque: keeps the epilogue's address arithmetic out of the k loop's registers
-    const int rowq = m0 + wm * WM + slot * 4;
+    int rowq = m0 + wm * WM + slot * 4;
+    asm volatile("" : "+v"(rowq));
     {
         if constexpr (NI_LDS > 0) {
             if (nt > 0) {
@@ -574,7 +703,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float x = acc[mi][ni][r] + bias;
+                        const float x = (AB ? 0.5f * acc[mi][ni][r] : acc[mi][ni][r]) + bias;   // (AB: the A bytes read as 2.0)
                         float p;
                         if (ACT == ACT_SIGMOID) p = sigmoidf_fast(x);
                         else if (ACT == ACT_RELU) p = fmaxf(x, 0.f);
@@ -691,7 +820,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // (d) row-major bf16 plane [M][ldo]: neighbouring lanes hold neighbouring columns; pair them up (even
     //     lane takes rows r = 0, 2, odd lane r = 1, 3), 4-byte writes into a bf16 patch of the whole tile,
     //     then whole rows leave as 16-byte chunks.  Columns past N (k padding of the next GEMM) are zeros.
-    if (g.out) {
+    if (g.out && g.out_bytes) {
+        // a 0/1 sample as a BYTE plane (0x40 = one; the next half step's A operand): bytes into a patch of the tile, whole
+        // rows out as 16-byte chunks; columns past N are zeros
+        constexpr int PROWB = BN + 16;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const bool col_ok = colb + ni * 16 < g.N;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    smem[(wm * WM + mi * 16 + slot * 4 + r) * PROWB + wn * WN + ni * 16 + l15] =
+                        (col_ok && xv[mi][ni][r] != 0.f) ? (unsigned char)0x40 : (unsigned char)0;
+        }
+        __syncthreads();
+        constexpr int CHB = BN / 16;   // 16-B chunks per row
+        unsigned char* plane = reinterpret_cast<unsigned char*>(g.out);
+#pragma unroll
+        for (int q8 = 0; q8 < (BM * CHB + NT - 1) / NT; ++q8) {
+            const int q = q8 * NT + tid, row = q / CHB, c = q % CHB;
+            const int gr = m0 + row, gc = n0 + 16 * c;
+            if (row < BM && gr < g.M && gc < g.ldo_cols)
+                *reinterpret_cast<u32x4*>(plane + (size_t)gr * g.ldo + gc) = *reinterpret_cast<const u32x4*>(smem + row * PROWB + 16 * c);
+        }
+    } else if (g.out) {
         const int odd = l15 & 1;
         const int npc = (g.out_pieces == 3) ? 3 : 1;     // a real-valued plane leaves as its three exact pieces
         for (int j = 0; j < npc; ++j) {
@@ -733,7 +886,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         }
     }
     KURBM_STAMP(ts[4]);
-#ifdef KURBM_STAMPS
+#if defined(KURBM_STAMPS) && !defined(KURBM_STAMPS_LOOP)   // (KURBM_STAMPS_LOOP: keep the k loop's micro-step sums)
     tu[0] = te[0] - ts[3]; tu[1] = te[1] - te[0]; tu[2] = te[2] ? te[2] - te[1] : 0; tu[3] = te[3] ? te[3] - te[2] : 0;
     tu[4] = te[3] ? ts[4] - te[3] : ts[4] - te[1]; tu[5] = 0;
 #endif
@@ -747,6 +900,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 // the combinations the host plans are instantiated
 template <int PBN, int E, int NZ>
 static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
+    if (g.a_bytes) {   // byte A planes: the half steps of the x3 path
+        if constexpr (E == EPI_HALFSTEP && PBN == 3) {
+            if (g.cfg == 2) hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+            else if (g.cfg == 0) hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (g.cfg == 2) {
         if constexpr (E == EPI_HALFSTEP) hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ>), dim3(nblk), dim3(768), 0, st, g);
         else return hipErrorInvalidValue;

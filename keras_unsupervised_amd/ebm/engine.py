@@ -266,8 +266,8 @@ class DeviceRBM:
         vp = self.v_pieces(v)
         if v_chain is not None and vp == 1:
             vp = 3 if mode == MODE_VISIBLE_GAUSSIAN else self.v_pieces(v_chain)
-        if vp == 1 and v.binary:
-            vp |= _lib.V_BINARY   # 0/1 data: the positive statistics run on the fp8 matrix cores (include/kurbm.h)
+        if vp == 1 and v.binary and (v_chain is None or v_chain.binary):
+            vp |= _lib.V_BINARY   # 0/1 data (and chain): byte / fp8 planes (include/kurbm.h)
         return vp
 
     def make_planes(self, v, windows, mode=MODE_VISIBLE_BERNOULLI, v_chain=None):

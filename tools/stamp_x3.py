@@ -54,6 +54,11 @@ lib.kurbm_debug_set_stamp_buffer(None)
 s = buf.cpu().numpy().astype(np.float64).reshape(4, 512, 8, 16)
 for n, name in enumerate(("vh sample", "hv sample", "vh prob", "statistics")):
     report(name, s[n, :, 0])
+    lw = s[n, :, 7]
+    lw = lw[lw[:, 0] == 1]
+    if len(lw):   # the first loader wave's loop: cycles summed over its tiles
+        print("           loader wave: issue %6.0f  wait for landing %6.0f  wait at the barrier %6.0f"
+              % tuple(np.median(lw[:, q]) for q in (1, 2, 3)))
     if n == 0:
         for wv in (1, 4, 5):
             report("  wave %d" % wv, s[n, :, wv])
