@@ -45,6 +45,7 @@ if ROOT not in sys.path:
 N_VIS, N_HID, BATCH = 784, 1024, 4096
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CU x 256 flop/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16
+PEAK_FP8_MFMA_TFLOPS = 5000.0         # MI355X_MICROARCH.md: dense fp8 (v_mfma_scale_f32_16x16x128_f8f6f4)
 BVH2 = 2.0 * BATCH * N_VIS * N_HID                 # one GEMM unit: B x V x H multiply-adds
 FLOP_HALF = BVH2                                   # one half-step GEMM
 FLOP_OUTER = 2 * BVH2                              # statistics GEMM: k = 2 x batch
@@ -186,7 +187,14 @@ def main():
             kern[name] = {"ms": ms, "tflops": flop / (ms * 1e-3) / 1e12, "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
         # the x3 launches, each alone, replayed on the planes of a complete x3 step (kurbm_cd_step_x3_stage)
         eng.cd_step(V, BATCH, 0, lr, seed, 0, compute="x3")
-        x3_units = {"x3_half_step_vh_sample": 3, "x3_half_step_hv_sample": 3, "x3_half_step_vh_prob": 3, "x3_stats_gemm": 4}
+        # GEMM units a launch EXECUTES: (bf16 units, fp8 units).  0/1 data: the positive statistics v_pos^T h_pos run on the
+        # fp8 matrix cores (KURBM_X3_F8POS, default on), the other products as three bf16 pieces of the real-valued operand
+        f8pos = os.environ.get("KURBM_X3_F8POS", "1") != "0"
+        x3_units = {"x3_half_step_vh_sample": (3, 0), "x3_half_step_hv_sample": (3, 0), "x3_half_step_vh_prob": (3, 0),
+                    "x3_stats_gemm": (3, 1) if f8pos else (4, 0)}
+
+        def mfma_roof_ms(u16, u8):   # the launch's MFMAs at the dense peaks of their types
+            return (u16 * BVH2 / (PEAK_BF16_MFMA_TFLOPS * 1e12) + u8 * BVH2 / (PEAK_FP8_MFMA_TFLOPS * 1e12)) * 1e3
         x3_algo = {"x3_half_step_vh_sample": FLOP_HALF, "x3_half_step_hv_sample": FLOP_HALF,
                    "x3_half_step_vh_prob": FLOP_HALF, "x3_stats_gemm": FLOP_OUTER}
         kern_x3 = {}
@@ -195,9 +203,10 @@ def main():
             ms = event_time_ms(lambda stage=stage: eng.cd_step_x3_stage(V, BATCH, 0, lr, seed, 0, stage), 50)
             kern_x3[name] = {"ms": ms}
             if name in x3_units:
-                ex = x3_units[name] * BVH2
-                kern_x3[name].update({"executed_bf16_tflops": ex / (ms * 1e-3) / 1e12,
-                                      "frac_of_bf16_peak": ex / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                u16, u8 = x3_units[name]
+                ex, roof = (u16 + u8) * BVH2, mfma_roof_ms(u16, u8)
+                kern_x3[name].update({"executed_tflops": ex / (ms * 1e-3) / 1e12, "units_bf16": u16, "units_fp8": u8,
+                                      "mfma_roof_ms": roof, "frac_of_mfma_roof": roof / ms,
                                       "algorithmic_tflops": x3_algo[name] / (ms * 1e-3) / 1e12})
         # ---- whole-step variants, same engine, HIP events (single GPU, local step) ---------------------------------
         def path(fn, units=None):
@@ -207,8 +216,8 @@ def main():
             if units is None:
                 r["frac_of_fp32_mfma_peak"] = tf / PEAK_F32_MFMA_TFLOPS
             else:
-                r["executed_bf16_tflops"] = units * BVH2 / (ms * 1e-3) / 1e12
-                r["executed_frac_of_bf16_peak"] = r["executed_bf16_tflops"] / PEAK_BF16_MFMA_TFLOPS
+                r["executed_tflops"] = units * BVH2 / (ms * 1e-3) / 1e12
+                r["executed_frac_of_bf16_peak"] = r["executed_tflops"] / PEAK_BF16_MFMA_TFLOPS
             return r
         pl1 = planes if planes is not None else eng.make_planes(V, [(0, BATCH)])
         paths = {"x3": path(lambda: eng.cd_step(V, BATCH, 0, lr, seed, 0, compute="x3", planes=pl1), X3_UNITS["binary"]),
@@ -237,15 +246,20 @@ def main():
             traffic_all = {}
         if args.compute == "x3":
             dom = max(x3_units, key=lambda k: kern_x3[k]["ms"])
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": kern_x3[dom]["executed_bf16_tflops"],
-                        "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": kern_x3[dom]["frac_of_bf16_peak"],
-                        "note": "EXECUTED bf16 MFMA flop of the launch (its pieces: 3 GEMM units per half step, 1 + 3 for the statistics; "
-                                "one unit = 2 B V H) against the dense bf16 peak, launch duration by HIP events in this run",
+            step16, step8 = (12, 1) if f8pos else (13, 0)
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": kern_x3[dom]["executed_tflops"],
+                        "peak": kern_x3[dom]["executed_tflops"] / kern_x3[dom]["frac_of_mfma_roof"], "unit": "TFLOP/s",
+                        "frac": kern_x3[dom]["frac_of_mfma_roof"],
+                        "note": "EXECUTED MFMA flop of the launch (3 GEMM units per half step: the three bf16 pieces of W; statistics: "
+                                "v_pos^T h_pos, 0/1 x 0/1, one unit on the fp8 matrix cores + three bf16 units for v_neg^T h_neg; one unit = "
+                                "2 B V H) over the launch duration (HIP events, this run); peak = that flop over the time its MFMAs "
+                                "take at the dense peaks of their types (bf16 2.5, fp8 5.0 PFLOP/s), frac = that time / the duration",
                         "traffic": traffic_all.get(dom, {}).get("hbm_bytes_per_launch"),
                         "traffic_source": "%s (rocprofv3 --pmc passes of an earlier run of this command; not measured in this run)" % traffic_file,
-                        "step": {"executed_bf16_tflops": X3_UNITS["binary"] * BVH2 / (ms_per_step * 1e-3) / 1e12 * world,
-                                 "frac": X3_UNITS["binary"] * BVH2 / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                                 "note": "all 13 bf16 GEMM units of a step over the timed step time, per GPU against the bf16 peak"},
+                        "step": {"executed_tflops": X3_UNITS["binary"] * BVH2 / (ms_per_step * 1e-3) / 1e12 * world,
+                                 "frac": mfma_roof_ms(step16, step8) / ms_per_step,
+                                 "note": "all 13 GEMM units of a step (%d bf16 + %d fp8): the time their MFMAs take at the dense peaks "
+                                         "over the timed step time, per GPU" % (step16, step8)},
                         "kernels": kern_x3, "kernels_fp32_path": kern}
         else:
             dom = max(kern, key=lambda k: kern[k]["ms"])

@@ -78,9 +78,9 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
         }
         tile[rq + 16 * j][q4 + 0] = v.x; tile[rq + 16 * j][q4 + 1] = v.y;
         tile[rq + 16 * j][q4 + 2] = v.z; tile[rq + 16 * j][q4 + 3] = v.w;
-        if (out && out_bytes) {   // 0/1 data as a byte plane (0x40 = one), ldo bytes between its rows
+        if (out && out_bytes) {   // 0/1 data as a byte plane (0x40 = one, k-permuted: kperm64), ldo bytes between its rows
             if (r < out_rows && c < ldo)
-                *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(out) + (size_t)r * ldo + c) =
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(out) + (size_t)r * ldo + kperm64(c)) =   // (c % 4 == 0)
                     (v.x != 0.f ? 0x40u : 0u) | (v.y != 0.f ? 0x4000u : 0u) | (v.z != 0.f ? 0x400000u : 0u) | (v.w != 0.f ? 0x40000000u : 0u);
         } else if (out && r < out_rows && c < ldo) store3(out + (size_t)r * ldo + c, out_plane, v.x, v.y, v.z, v.w);   // ldo % 8 == 0
     }

@@ -71,4 +71,10 @@ __device__ __forceinline__ uint32_t bf16_piece_bits(float x, int j) {
     return f32_to_bf16_bits(x);
 }
 
+
+// Byte planes of 0/1 values (A operand of k_gemm_pb<..., AB>) are K-PERMUTED inside every group of 64 elements: element
+// 32 ks + 8 s + j (j < 8) of a group sits at byte 16 s + 8 ks + j, so that the bytes of both k-steps which lane group s of the
+// MFMA operand needs are 16 consecutive bytes.  c -> the position of column c in its row.
+__host__ __device__ inline int kperm64(int c) { return (c & ~0x38) | ((c & 0x18) << 1) | ((c & 0x20) >> 2); }
+
 }  // namespace kurbm

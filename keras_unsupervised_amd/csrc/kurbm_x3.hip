@@ -73,7 +73,11 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // that is the bf16 value 2.0, and the epilogue halves the sum (exact).  Half the bytes of the A operand from L2 and through
 // LDS (with DMA staging a tile's time follows the 128-byte lines it takes in).  So that the lines stay whole, an A row in
 // LDS is 128 BYTES = 128 k, an A BLOCK that serves two 64-deep k-tiles: two block buffers beside the two B stages, half a
-// block requested per tile.  The MFMA waves read 8-byte fragments and expand them with four v_perm_b32 per k-step.
+// block requested per tile.  A byte plane is stored K-PERMUTED inside every group of 64 elements: element 32 ks + 8 s + j
+// (k-step ks, lane group s of the MFMA operand, j < 8) sits at byte 16 s + 8 ks + j, so that the 16 bytes a lane needs for
+// BOTH k-steps of a tile are one ds_read_b128 -- the very chunk / swizzle / bank pattern of the bf16 fragments (two
+// 8-byte reads per tile fused into ds_read2_b64 and cost 27 % of the LDS cycles in bank conflicts).  The MFMA waves
+// expand a k-step's 8 bytes with four v_perm_b32.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int PB, int EPI, int NOISE, bool AB = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES_N + 256) / 256) void k_gemm_pb(GemmArgsB g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;          // threads of the MFMA waves (and of every epilogue loop)
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    typedef std::conditional_t<AB, u32x2, u32x4> afrag;   // (a byte fragment is 8 bytes; it is expanded where it is used)
+    typedef u32x4 afrag;   // (AB: fa[0] = the 16 bytes of BOTH k-steps of a tile, expanded per k-step into fx; fa[1] unused)
     afrag fa[2][TM];
     u32x4 fb[3][TN];   // fragment buffers: A by k-step; B by micro-step (three: read two steps ahead)
     // fragment rows are l15 + a multiple of 16, so their swizzle key is (l15 >> 1) & 7
@@ -262,11 +266,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // AB: `ablk` = the block buffer (0 / 1) of the tile pair in work; tile `buf` (= its parity) is half `buf` of the block's k
     int ablk = 0;
     auto frag_a = [&](int buf, int ks, afrag (&f)[TM], int blk_step = 0) __attribute__((always_inline)) {
-        if constexpr (AB) {   // k = 64 buf + 32 ks + 8 slot ...: chunk 4 buf + 2 ks + slot / 2 of the 128-byte row, its half slot % 2
-            const unsigned char* c = smem + ((ablk + blk_step) & 1) * A_BYTES + (wm * WM + l15) * ROWB +
-                                     16 * ((4 * buf + 2 * ks + (slot >> 1)) ^ swz) + 8 * (slot & 1);
+        if constexpr (AB) {   // tile `buf` of the block, lane group `slot`: chunk 4 buf + slot of the 128-byte row (k-permuted plane)
+            if (ks == 0) {
+                const unsigned char* c = smem + ((ablk + blk_step) & 1) * A_BYTES + (wm * WM + l15) * ROWB + 16 * ((4 * buf + slot) ^ swz);
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x2*>(c + mi * 16 * ROWB);
+                for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
+            }
         } else {
             const unsigned char* c = smem + buf * STAGE + (wm * WM + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
 #pragma unroll
@@ -282,12 +287,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // k-step, behind the last MFMAs of the step before (so the permutes run while the matrix pipe drains those); raw
     // double buffer + this = the registers of the bf16 fragments
     [[maybe_unused]] u32x4 fx[AB ? TM : 1];
-    auto expand_a = [&](const afrag (&a)[TM]) __attribute__((always_inline)) {
+    auto expand_a = [&](int ks) __attribute__((always_inline)) {
         if constexpr (AB) {
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-                fx[mi] = u32x4{__builtin_amdgcn_perm(0u, a[mi].x, 0x010C000Cu), __builtin_amdgcn_perm(0u, a[mi].x, 0x030C020Cu),
-                               __builtin_amdgcn_perm(0u, a[mi].y, 0x010C000Cu), __builtin_amdgcn_perm(0u, a[mi].y, 0x030C020Cu)};
+            for (int mi = 0; mi < TM; ++mi) {
+                const uint32_t lo = ks ? fa[0][mi].z : fa[0][mi].x, hi = ks ? fa[0][mi].w : fa[0][mi].y;
+                fx[mi] = u32x4{__builtin_amdgcn_perm(0u, lo, 0x010C000Cu), __builtin_amdgcn_perm(0u, lo, 0x030C020Cu),
+                               __builtin_amdgcn_perm(0u, hi, 0x010C000Cu), __builtin_amdgcn_perm(0u, hi, 0x030C020Cu)};
+            }
         }
     };
     auto mfmas = [&](const afrag (&a)[TM], const u32x4 (&b)[TN]) __attribute__((always_inline)) {
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 }
                 if (AB && (u + 1) % NPB == 0) {   // the NEXT k-step's, behind this step's MFMAs (same registers: not among them)
                     __builtin_amdgcn_sched_barrier(0);
-                    expand_a(fa[((u + 1) / NPB) & 1]);
+                    expand_a(((u + 1) / NPB) & 1);
                 }
 #ifdef KURBM_STAMPS
                 KURBM_STAMP(tq[u + 1]);
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             mfmas(fa[ks & 1], fb[u & 1]);
             if (AB && (u + 1) % NPB == 0) {
                 __builtin_amdgcn_sched_barrier(0);
-                expand_a(fa[((u + 1) / NPB) & 1]);
+                expand_a(((u + 1) / NPB) & 1);
             }
 #ifdef KURBM_STAMPS
             KURBM_STAMP(tq[u + 1]);
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         __syncthreads();
         frag_a(0, 0, fa[0]);
         frag_b(0, 0, 0, fb[0]);
-        expand_a(fa[0]);
+        expand_a(0);
         KURBM_STAMP(ts[1]);
         // unrolled by two: the LDS buffers alternate statically
         int i = 0;
@@ -821,8 +828,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     //     lane takes rows r = 0, 2, odd lane r = 1, 3), 4-byte writes into a bf16 patch of the whole tile,
     //     then whole rows leave as 16-byte chunks.  Columns past N (k padding of the next GEMM) are zeros.
     if (g.out && g.out_bytes) {
-        // a 0/1 sample as a BYTE plane (0x40 = one; the next half step's A operand): bytes into a patch of the tile, whole
-        // rows out as 16-byte chunks; columns past N are zeros
+        // a 0/1 sample as a BYTE plane (0x40 = one; the next half step's A operand, k-permuted: kurbm_device.h kperm64): bytes
+        // into a patch of the tile, whole rows out as 16-byte chunks; columns past N are zeros
         constexpr int PROWB = BN + 16;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
@@ -831,7 +838,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    smem[(wm * WM + mi * 16 + slot * 4 + r) * PROWB + wn * WN + ni * 16 + l15] =
+                    smem[(wm * WM + mi * 16 + slot * 4 + r) * PROWB + kperm64(wn * WN + ni * 16 + l15)] =
                         (col_ok && xv[mi][ni][r] != 0.f) ? (unsigned char)0x40 : (unsigned char)0;
         }
         __syncthreads();

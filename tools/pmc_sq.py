@@ -11,7 +11,8 @@ LABEL = {
     ("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true>", 256): "x3_half_step_vh_sample",
     ("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true>", 224): "x3_half_step_hv_sample",
     ("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 0, true>", 256): "x3_half_step_vh_prob",
-    ("k_gemm_pb<128, 128, 2, 4, 64, 3, 1, 0, true>", 224): "x3_stats_gemm",
+    ("k_gemm_pb<128, 128, 2, 4, 64, 3, 1, 0, true>", 224): "x3_stats_gemm",      # (rounds 1-2a: last argument = wave-specialised)
+    ("k_gemm_pb<128, 128, 2, 4, 64, 3, 1, 0, false>", 224): "x3_stats_gemm",     # (since: last argument = A is a byte plane)
 }
 out = collections.defaultdict(dict)
 for path in sys.argv[2:]:

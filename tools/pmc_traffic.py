@@ -21,7 +21,8 @@ def load(path, counter):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 label = {}
-for ws in ("", ", true"):      # plain and wave-specialised instantiations
+# (the last template argument: round 1 / early round 2 "wave-specialised", since then "A operand is a byte plane")
+for ws in ("", ", true", ", false"):
     label[("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 1%s>" % ws, 256)] = "x3_half_step_vh_sample"
     label[("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 1%s>" % ws, 224)] = "x3_half_step_hv_sample"
     label[("k_gemm_pb<128, 128, 2, 4, 64, 3, 0, 0%s>" % ws, 256)] = "x3_half_step_vh_prob"
@@ -30,6 +31,8 @@ for ws in ("", ", true"):      # plain and wave-specialised instantiations
 label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true>", 256)] = "x3_half_step_vh_sample"
 label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true>", 224)] = "x3_half_step_hv_sample"
 label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 0, true>", 256)] = "x3_half_step_vh_prob"
+for nz, wgs, name in ((1, 256, "x3_half_step_vh_sample"), (1, 224, "x3_half_step_hv_sample"), (0, 256, "x3_half_step_vh_prob")):
+    label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, %d, false>" % nz, wgs)] = name      # (real-valued A operand: bf16 planes)
 out = {}
 for key in sorted(set(fetch) | set(write)):
     name = label.get(key)
