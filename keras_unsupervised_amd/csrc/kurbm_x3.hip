@@ -105,7 +105,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     constexpr int PROW16 = 2 * BN + 16;   // bf16 patch row (bytes)
     constexpr int PROW32 = 4 * BN + 16;   // fp32 patch row (bytes)
     constexpr int PATCH_BYTES = (EPI == EPI_SOFTPLUS) ? WAVES_N * BM * 4 : BM * (EPI == EPI_SLAB ? PROW32 : PROW16);
-    constexpr int STAGES_BYTES = 2 * (A_BYTES + B_BYTES);
+    // One-piece tiles (the rounded-bf16 path) are 16 MFMAs per wave, shorter than the round trip of a tile's DMA: THREE
+    // stages, tiles requested two ahead.  (Three-piece tiles: two stages fill the LDS.)
+    constexpr int NSTG = (PB == 1) ? 3 : 2;
+    static_assert(!(AB && NSTG != 2), "A blocks: two stages");
+    constexpr int STAGES_BYTES = NSTG * (A_BYTES + B_BYTES);
     constexpr int SMEM_BYTES = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
     // the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
     // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
@@ -347,8 +351,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #define KURBM_NEXT_READ_AT (KURBM_BARRIER_AT == 5 ? 5 : KURBM_BARRIER_AT + 1)
 #endif
                 if (u == KURBM_NEXT_READ_AT) {
-                    frag_a(cur ^ 1, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
-                    frag_b(cur ^ 1, 0, 0, fb[0]);
+                    frag_a((cur + 1) % NSTG, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
+                    frag_b((cur + 1) % NSTG, 0, 0, fb[0]);
                 }
                 mfmas(fa[ks & 1], fb[u % 3]);
                 if (KURBM_BARRIER_AT == 3 && u == 3) {
@@ -373,8 +377,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             } else {
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
-                frag_a(cur ^ 1, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
-                frag_b(cur ^ 1, 0, 0, fb[0]);
+                frag_a((cur + 1) % NSTG, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
+                frag_b((cur + 1) % NSTG, 0, 0, fb[0]);
             }
             mfmas(fa[ks & 1], fb[u & 1]);
             if (AB && (u + 1) % NPB == 0) {
@@ -411,8 +415,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
-            frag_a(cur ^ 1, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
-            frag_b(cur ^ 1, 0, 0, fb[0]);
+            frag_a((cur + 1) % NSTG, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
+            frag_b((cur + 1) % NSTG, 0, 0, fb[0]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -526,6 +530,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     KURBM_LSTAMP(3);
                 }
                 KURBM_LSTAMP_OUT();
+            } else if constexpr (NSTG == 3) {
+                // ring of three stages: while tile i is multiplied, tile i + 1 is landing and tile i + 2 is requested into the
+                // stage tile i - 1 has left; a counted vmcnt leaves the youngest tile's pieces in flight across the barrier
+                constexpr int NP = NA + NB1;   // (one-piece tiles: pieces per loader wave and tile)
+                dma_tile(0, tile_of(t_begin));
+                if (nt > 1) dma_tile(1, tile_of(t_begin + 1));
+                if (nt > 1) __builtin_amdgcn_s_waitcnt(vm(NP)); else __builtin_amdgcn_s_waitcnt(VM0);
+                __builtin_amdgcn_s_barrier();
+                int nb = 2;   // stage of tile i + 2
+                for (int i = 0; i < nt; ++i) {
+                    if (i + 2 < nt) {
+                        dma_tile(nb, tile_of(t_begin + i + 2));
+                        __builtin_amdgcn_s_waitcnt(vm(NP));
+                    } else {
+                        __builtin_amdgcn_s_waitcnt(VM0);
+                    }
+                    nb = nb == 2 ? 0 : nb + 1;
+                    __builtin_amdgcn_s_barrier();
+                }
             } else {
             // both stages are free at the start: tiles 0 and 1 are requested back to back, and the first barrier waits for
             // tile 0's pieces only (a counted vmcnt leaves tile 1's in flight)
@@ -587,12 +610,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         KURBM_STAMP(ts[1]);
         // unrolled by two: the LDS buffers alternate statically
         int i = 0;
-        for (; i + 1 < nt; i += 2) {
-            tile_any(0, tile_of(t_begin + i));
-            tile_any(1, tile_of(t_begin + i + 1));
-            ablk ^= 1;
+        if constexpr (NSTG == 3) {
+            for (; i + 2 < nt; i += 3) {
+                tile_any(0, tile_of(t_begin + i));
+                tile_any(1, tile_of(t_begin + i + 1));
+                tile_any(2, tile_of(t_begin + i + 2));
+            }
+            if (i < nt) tile_any(0, tile_of(t_begin + i));
+            if (i + 1 < nt) tile_any(1, tile_of(t_begin + i + 1));
+        } else {
+            for (; i + 1 < nt; i += 2) {
+                tile_any(0, tile_of(t_begin + i));
+                tile_any(1, tile_of(t_begin + i + 1));
+                ablk ^= 1;
+            }
+            if (i < nt) tile_any(0, tile_of(t_begin + i));
         }
-        if (i < nt) tile_any(0, tile_of(t_begin + i));
     }
     __syncthreads();
     KURBM_STAMP(ts[2]);
