@@ -13,24 +13,21 @@
 // 0 .. npb-1 of B of the same set; set 1 is the negative phase of the statistics (its B planes are stored negated).  A
 // real-valued A (grey-level data) is three segments (ia = 0, 1, 2 with npb = 3, 2, 1).
 //
-// Tile 128 x 128, k-tile 64 (swizzled 128-byte LDS rows), 8 waves (2 x 4, 64 x 32 outputs each), two per SIMD: while one waits for
-// LDS or the barrier the other issues MFMAs.  B fragments are read two micro-steps ahead; the eight loads of a
-// tile are issued one part per micro-step.  Staging global -> registers -> LDS with buffer loads (a
-// constant per-lane offset + one scalar offset per tile: no vector address arithmetic in the loop),
-// double-buffered in LDS, fetched two tiles ahead, one barrier per tile.
+// Tile 128 x 128 (statistics) or 256 x 64 (half steps), k-tile 64 (swizzled 128-byte LDS rows), 8 MFMA waves of 64 x 32
+// outputs, two per SIMD (while one waits for LDS or the barrier the other issues MFMAs), beside 4 loader waves that stage by
+// LDS-DMA (below).  B fragments are read two micro-steps ahead.  Two LDS stages, one barrier per tile; one-piece tiles (the
+// rounded-bf16 path) three stages, tiles requested two ahead.
 //
-// Epilogue of a half step, from registers: bias + activation + Philox draw; column sums of the value
-// plane (bias statistics); the transposed bf16 plane(s) as 8-byte stores (a lane holds 4 consecutive
-// rows of its column); only the row-major bf16 plane takes a trip through LDS (bf16 patch of the whole
-// tile, then 16-byte coalesced rows).
+// Epilogue of a half step, from registers: bias + activation + Philox draw; column sums of the value plane (bias
+// statistics); the transposed plane(s) as 8-byte (bf16) or 4-byte (fp8) stores (a lane holds 4 consecutive rows of its
+// column); only the row-major plane (bytes of a 0/1 sample, else bf16) takes a trip through LDS (patch of the whole tile,
+// then 16-byte coalesced rows).
 //
-// Measured (MI355X, config 2, round 2; DESIGN.md section 4, profiles/r02_b_*): half steps 27-28 us on 256 x 64 tiles (about
-// 4 us until the first tile has landed, 17 us of k loop, 2-3 us draw + sigmoid, 3-4 us of plane stores), the statistics GEMM
-// 36 us; 700-750 executed bf16 TFLOP/s per launch, MFMA busy 36-42 %, L2 hit rate 81 % with the XCD 2-D blocks.  Tried and
-// dropped (git history): pieces loaded straight into registers without LDS (15 % slower), padded leading
-// dimensions, staggered k walks, row-tile-fastest block order (all equal), Philox calls spread over the k loop through
-// wave-uniform selects (scratch), four MFMA waves of 128 x 32 outputs (25-75 % slower), 0/1 planes as bytes (timing-only
-// build KURBM_ABLATE=4: 2-6 %, not worth the rewrite).
+// Measured (MI355X, config 2, end of round 2; DESIGN.md section 4, profiles/r02_e_*, r02_f_*): sampling half steps 25.2 us, vh
+// prob 24.8 (about 4 us until the first tile has landed, 14 tiles of about 2 100 cycles for 1 536 of MFMA issue, 2-3 us draw
+// + sigmoid, 3-4 us of plane write-back), the statistics GEMM 28.7 us; MFMA busy 39-46 %, L2 hit rate 76-80 %, LDS bank
+// conflicts <= 1.5 %.  What bounds the loop (the loaders' DMA round trip on bf16 planes, the MFMA waves on byte planes) and
+// everything that was tried and dropped: DESIGN.md section 4.
 //
 // Reference op sequences: ku/ebm/rbm.py:46-47 (v->h), :52-53 / :121-123 (h->v), :124 (h_neg), :125-134
 // (statistics); the split is an implementation choice of this build.
