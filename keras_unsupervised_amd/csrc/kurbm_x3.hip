@@ -456,9 +456,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         biasv[ni] = (EPI == EPI_HALFSTEP && c < g.N) ? g.bias[c] : 0.f;
     }
     if (loader) {
-#ifdef KURBM_LOADER_PRIO
-        __builtin_amdgcn_s_setprio(KURBM_LOADER_PRIO);
-#endif
         // ---- loader waves: a loop of their own; one barrier per tile, like the MFMA waves.  `buffer_load_dwordx4 ... lds`,
         // one 1-KiB piece (8 rows of a tile) per wave instruction, straight into the stage that the barrier before has
         // freed; the wait for a tile's pieces and then the tile's barrier make them visible to the MFMA waves
@@ -595,10 +592,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 }
         }
     }
-#ifndef KURBM_MFMA_PRIO
-#define KURBM_MFMA_PRIO 2
-#endif
-    __builtin_amdgcn_s_setprio(KURBM_MFMA_PRIO);   // the MFMA waves go first wherever a loader wave competes for issue
+    __builtin_amdgcn_s_setprio(2);   // the MFMA waves go first wherever a loader wave competes for issue (the reverse: no difference)
     if (nt > 0) {
         __syncthreads();
         frag_a(0, 0, fa[0]);
