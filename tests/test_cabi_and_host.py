@@ -139,3 +139,11 @@ def test_shard_rows_fixed_ownership_for_persistent_chains():
             for (lo, hi), (flo, fhi) in zip(part, full):
                 assert lo == min(flo, n) and hi == min(fhi, n)
             assert part[0][0] == 0 and max(hi for _, hi in part) == n
+
+
+def test_graft_entry_build_check_matches_the_abi():
+    """__graft_entry__.build() must not pin an ABI number of its own (it once asserted the previous one)."""
+    import inspect
+    import __graft_entry__ as g
+    src = inspect.getsource(g.build)
+    assert "_lib.ABI_VERSION" in src
