@@ -312,7 +312,9 @@ int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
  * Resident data planes.  RBM.fit slices the same matrix V every epoch (rbm.py:113, :211), so its bf16 images -- the pieces
  * of the rows row-major and transposed, and their column sums per 64-row band -- are made ONCE per window of rows and a
  * step given opts->v_planes reads them instead of converting the window again.  `planes` is caller-owned device memory of
- * kurbm_x3_planes_bytes(rows) bytes per window; its layout follows `rows` (a remainder batch has its own).
+ * kurbm_x3_planes_bytes(rows) bytes per window; its layout follows `rows` (a remainder batch has its own) and v_pieces:
+ * with 1 | KURBM_V_BINARY the row-major plane holds bytes and the transposed one fp8 (see above), so the steps that read a
+ * window must pass the v_pieces it was made with, under the same KURBM_X3_BYTES / KURBM_X3_F8POS settings of the context.
  */
 size_t kurbm_x3_planes_bytes(kurbm_ctx* ctx, int rows, int n_vis, int v_pieces);
 int kurbm_x3_convert_rows(kurbm_ctx* ctx, const float* v, int rows, int ldv, int n_vis, int v_pieces, void* planes,
