@@ -710,7 +710,9 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
     const bool vh = (layout == LAYOUT_VH);
     g.A0 = A; g.lda = lda; g.a_plane0 = a_plane;
     g.B0 = vh ? m.Wtb : m.Wb; g.ldb = vh ? m.ldWt : m.ldW; g.b_plane0 = vh ? m.planeWt : m.planeW;
-    g.M = rows; g.N = vh ? p->n_hid : p->n_vis; g.K = vh ? m.Kv : m.Kh;
+    // k extent: whole 64-deep k-tiles over the units (the planes and the mirror are zero-padded to 128 beyond them, so the
+    // last tile reads zeros past n; 784 visibles are 13 tiles, not the 14 of the padded extent)
+    g.M = rows; g.N = vh ? p->n_hid : p->n_vis; g.K = round_up(vh ? p->n_vis : p->n_hid, 64);
     {
         // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip); rounded bf16: against its one piece
         g.nseg = pb_codes(ctx, a_pieces, m.pieces, 0u, &g.seg_codes, 0);

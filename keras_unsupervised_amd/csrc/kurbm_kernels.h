@@ -143,7 +143,7 @@ struct GemmArgsB {
     const uint16_t* baseB;
     uint32_t offA0, offA1, offB0, offB1;
     int lda, ldb;         // elements, multiples of 8
-    int M, N, K;          // K per segment, multiple of 128
+    int M, N, K;          // K per segment, multiple of 64 (the operands are zero-padded to 128)
     int nseg, nkt, kt_total, kt_per_split, nsplit;
     int grid_m, grid_n;
     int m_fastest;
