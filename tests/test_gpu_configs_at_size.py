@@ -125,6 +125,38 @@ def test_config2_x3_stagewise(gpu_device):
     assert flips < 64
 
 
+@pytest.mark.parametrize("knobs", [dict(KURBM_X3_F8POS=0), dict(KURBM_X3_BYTES=0), dict(KURBM_X3_F8POS=0, KURBM_X3_BYTES=0)])
+def test_config2_x3_plane_formats_agree(gpu_device, knobs):
+    """configs[1] at size: the step with 0/1 planes as bytes and the positive statistics on fp8 (the default for 0/1 data)
+    against the same step with bf16 planes (`KURBM_X3_BYTES=0`) and / or bf16 positive statistics (`KURBM_X3_F8POS=0`).  The
+    chains are bit-identical (a byte plane holds the same 0/1 values; the halved sums are exact), so the visible-bias sums
+    and both bias sums match to the bit; dW matches to the order of the fp32 additions in the statistics GEMM."""
+    from keras_unsupervised_amd._lib import Context
+    B, nv, nh = 4096, 784, 1024
+    W0 = synthetic_params(nv, nh, seed=1)
+    v = synthetic_binary(B, nv, seed=1234)
+    ctx = Context.get(gpu_device.index)
+    got = []
+    try:
+        for kn in ({}, knobs):
+            for name, value in kn.items():
+                ctx.set_option(name, value)
+            e = _engine(*W0, gpu_device)
+            vd = _dm(v, gpu_device)
+            planes = e.make_planes(vd, [(0, B)])
+            e.cd_step(vd, B, 0, 1e-3 / B, 42, 17, apply=False, emit_delta=True, compute="x3", planes=planes)
+            torch.cuda.synchronize()
+            d = e.delta_buffer().cpu().numpy()
+            got.append((d[: nv * nh].reshape(nv, nh), d[nv * nh: nv * nh + nh], d[nv * nh + nh:]))
+    finally:
+        for name in knobs:
+            ctx.set_option(name, 1)
+    (dW0, dbh0, dbv0), (dW1, dbh1, dbv1) = got
+    assert np.array_equal(dbv0, dbv1)                                   # sums of 0/1 values: exact whatever the plane format
+    assert np.array_equal(dbh0, dbh1)                                   # ... and so is h_neg: doubling commutes with fp32 rounding
+    assert np.max(np.abs(dW0 - dW1)) <= 2e-6 * max(1.0, float(np.abs(dW1).max()))
+
+
 @pytest.mark.parametrize("compute", ["x3", "fp32"])
 def test_config2_gaussian_default_mode_stagewise(gpu_device, compute):
     """configs[1]'s shape in the reference's DEFAULT mode (MODE_VISIBLE_GAUSSIAN, rbm.py:22) on grey-level data: relu-threshold
