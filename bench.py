@@ -270,8 +270,8 @@ def main():
                         "step": {"algorithmic_tflops": FLOP_STEP / (ms_per_step * 1e-3) / 1e12 * world,
                                  "frac": FLOP_STEP / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
                         "kernels": kern, "kernels_x3_path": kern_x3}
-        dtype = ("f32 (storage, accumulation, results); products as exact bf16 triples on the bf16 MFMA (x3)"
-                 if args.compute == "x3" else "f32")
+        dtype = ("f32 (storage, accumulation, results); products as exact bf16 triples on the bf16 MFMA (x3), the 0/1 x 0/1 "
+                 "product of the positive statistics on the fp8 MFMA (exact)" if args.compute == "x3" else "f32")
         out = {
             "metric": "cd1_gibbs_steps_per_sec", "value": value,
             "unit": "steps/s (1 step = CD-1 update over 4096 rows, 784x1024 fp32)",
