@@ -38,16 +38,17 @@ def test_header_is_plain_c_and_structs_match(tmp_path):
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "kurbm.h"\n'
         'int main(void) {\n'
-        '  printf("%zu %zu %zu %zu %zu %zu %d %d\\n", sizeof(kurbm_params), offsetof(kurbm_params, W), sizeof(kurbm_rng),\n'
+        '  printf("%zu %zu %zu %zu %zu %zu %d %d %d\\n", sizeof(kurbm_params), offsetof(kurbm_params, W), sizeof(kurbm_rng),\n'
         '         sizeof(kurbm_cd_opts), offsetof(kurbm_cd_opts, v_planes), offsetof(kurbm_cd_opts, seed),\n'
-        '         KURBM_ABI_VERSION, KURBM_UNIQUE_ID_BYTES);\n'
+        '         KURBM_ABI_VERSION, KURBM_UNIQUE_ID_BYTES, KURBM_V_BINARY);\n'
         '  return 0; }\n')
     exe = tmp_path / "abi"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert [int(x) for x in out] == [C.sizeof(_lib.Params), _lib.Params.W.offset, C.sizeof(_lib.Rng), C.sizeof(_lib.CdOpts),
-                                     _lib.CdOpts.v_planes.offset, _lib.CdOpts.seed.offset, _lib.ABI_VERSION, _lib.UNIQUE_ID_BYTES]
+                                     _lib.CdOpts.v_planes.offset, _lib.CdOpts.seed.offset, _lib.ABI_VERSION, _lib.UNIQUE_ID_BYTES,
+                                     _lib.V_BINARY]
 
 
 def test_struct_layouts_match_header():
