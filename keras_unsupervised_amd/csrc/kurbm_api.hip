@@ -19,13 +19,14 @@ using namespace kurbm;
 // Experiment knobs.  Every one is read from the environment ONCE, at kurbm_ctx_create, into the context (no getenv on
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
-enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
+enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
        KN_UNFUSED_MIRROR, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
     {"KURBM_X3_F8POS", 1},         // 0: the positive statistics of 0/1 data stay on bf16 planes
     {"KURBM_X3_BYTES", 1},         // 0: the row-major planes of 0/1 samples / data stay bf16 (1: bytes, half the A tiles)
+    {"KURBM_X3_STATS_TALL", 1},    // 0: 128 x 128 tiles for the x3 statistics GEMM (1: 256 x 64 where n_vis > 128)
     {"KURBM_BF16_SPLIT", KN_AUTO}, // split-K slices of the bf16 / x3 statistics GEMM
     {"KURBM_X3_FULL", 0},          // 1: all nine piece pairs of a real x real product
     {"KURBM_X3_TALL", KN_AUTO},    // 0 / 1: never / always 256 x 64 half-step tiles
@@ -592,15 +593,18 @@ struct WorkspaceB {
     size_t slab_stride, bytes;
 };
 
-struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_split, ld_slab; };
+struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_split, ld_slab, cfg; };
 
 // the statistics GEMM on k_gemm_pb: k-tile 64, one workgroup per CU, nseg segments walked fastest, so a slice is a whole
 // number of k positions
 static OuterPlanB plan_outer_bf16(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, int nseg, int s_max = 1 << 30,
-                                  bool f8pos = false) {
+                                  bool f8pos = false, bool x3 = false) {
     OuterPlanB pl;
-    pl.gm = ceil_div(n_vis, 128);
-    pl.gn = ceil_div(n_hid, 128);
+    // x3: 256 x 64 tiles -- the three-piece B tile is the heavy operand (3 x 8 KB against 3 x 16), so a k-tile is 56 KB instead
+    // of 64 for the same MFMAs, and 784 x 1024 fills 256 workgroups instead of 224 (statistics GEMM 28.5 -> 27.4 us)
+    pl.cfg = (x3 && ctx->knob[KN_X3_STATS_TALL] != 0 && n_vis > 128) ? 2 : 0;
+    pl.gm = ceil_div(n_vis, pl.cfg == 2 ? 256 : 128);
+    pl.gn = ceil_div(n_hid, pl.cfg == 2 ? 64 : 128);
     // f8pos: the walk is in units of 128 k -- one fp8 tile of segment 0, two 64-deep tiles of every other segment
     const int per = f8pos ? 2 * nseg - 1 : nseg;
     pl.nkt = round_up(rows, 128) / (f8pos ? 128 : 64);
@@ -642,7 +646,7 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.planeV = (size_t)w.Kb * w.Lv;
     w.planeVT = (size_t)n_vis * w.Lb;
     w.planeHT = (size_t)n_hid * w.Lb;
-    const OuterPlanB pl = plan_outer_bf16(ctx, rows, n_vis, n_hid, pieces == 3 ? v_pieces + 1 : 2);
+    const OuterPlanB pl = plan_outer_bf16(ctx, rows, n_vis, n_hid, pieces == 3 ? v_pieces + 1 : 2, 1 << 30, false, pieces == 3);
     w.slab_stride = (size_t)n_vis * pl.ld_slab;
     char* b = static_cast<char*>(base);
     size_t off = 0;
@@ -907,12 +911,12 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
     // segments: (piece of v_pos) x h_pos, then v_neg x (piece of -h_neg)
     const int nseg_st = pieces == 3 ? v_pieces + vn_pieces : 2;
-    const OuterPlanB plf = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, nseg_st, 1 << 30, f8pos);
+    const OuterPlanB plf = plan_outer_bf16(ctx, rows, p->n_vis, p->n_hid, nseg_st, 1 << 30, f8pos, pieces == 3);
     const int Mr = m_hi - m_lo;                         // visible rows of this call (all of them unless only == 7)
     const bool sub = (Mr != p->n_vis);
     // a row range keeps inside the slab memory carved for the whole matrix
     const OuterPlanB pl = sub ? plan_outer_bf16(ctx, rows, Mr, p->n_hid, nseg_st,
-                                                (int)((w.slab_stride * plf.nsplit_bound) / ((size_t)Mr * plf.ld_slab)), f8pos)
+                                                (int)((w.slab_stride * plf.nsplit_bound) / ((size_t)Mr * plf.ld_slab)), f8pos, pieces == 3)
                               : plf;
     const size_t slab_stride = sub ? (size_t)Mr * pl.ld_slab : w.slab_stride;
     int nslab_used = pl.nsplit;
@@ -932,7 +936,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
         if (f8pos) { g.f8pos = 1; g.inv_nseg = inv_of(2 * g.nseg - 1); }   // (tiles per 128-deep unit)
         g.m_fastest = ctx->knob[KN_X3_STATS_MFAST];
-        g.cfg = 0;
+        g.cfg = pl.cfg;
         g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
         g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
         HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));

@@ -942,7 +942,8 @@ static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
         }
     }
     if (g.cfg == 2) {
-        if constexpr (E == EPI_HALFSTEP) hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ>), dim3(nblk), dim3(768), 0, st, g);
+        if constexpr (E == EPI_HALFSTEP || (E == EPI_SLAB && PBN == 3))
+            hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ>), dim3(nblk), dim3(768), 0, st, g);
         else return hipErrorInvalidValue;
     } else if (g.cfg == 0) {
         hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ>), dim3(nblk), dim3(768), 0, st, g);
