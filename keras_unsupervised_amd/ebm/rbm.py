@@ -60,8 +60,8 @@ class RBM(object):
         # how the matrix products of fit() run (extension; storage, accumulation and results are fp32 in all):
         #   'fp32'  fp32 MFMA               'x3'  fp32 values as exact bf16 triples on the bf16 MFMA
         #   'bf16'  operands ROUNDED to bf16 (reduced precision, BASELINE.json config 5)
-        #   'auto'  (default) 'x3' at batch sizes >= 1024, else 'fp32' (whose
-        #           whole-epoch call serves small batches better)
+        #   'auto'  (default) 'x3' at batch sizes >= 512, else 'fp32' (tools/bench_fit.py, 784 x 1024, us per step fp32 / x3:
+        #           batch 256 95 / 98, 512 101 / 97, 1024 120 / 105, 4096 332 / 141)
         self.compute_dtype = str(opt("compute_dtype", "auto"))
         if self.compute_dtype not in ("fp32", "x3", "bf16", "auto"):
             raise ValueError("compute_dtype must be 'fp32', 'x3', 'bf16' or 'auto'")
@@ -322,7 +322,7 @@ class RBM(object):
 
     def _compute(self):
         if self.compute_dtype == "auto":
-            return "x3" if int(self.hps["batch_size"]) >= 1024 else "fp32"
+            return "x3" if int(self.hps["batch_size"]) >= 512 else "fp32"
         return self.compute_dtype
 
     def _update_local(self, Vd, lo, rows, lr, step):
