@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_COUNT };
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
@@ -33,6 +33,8 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_X3_MFAST", 1},         // block order of the x3 half steps
     {"KURBM_X3_STATS_MFAST", 0},   // block order of the x3 statistics GEMM
     {"KURBM_UNFUSED_MIRROR", 0},   // 1: slab reduce and weight-piece mirror as two launches
+    {"KURBM_X3_XCD2D", 1},         // 0: linear block order of k_gemm_pb instead of one 2-D block of tiles per XCD
+    {"KURBM_REDUCE_TR", 0},        // tile height (16 / 32 / 64) of the slab-reduce + mirror launch; 0: by the grid it makes
 };
 
 struct kurbm_ctx {
@@ -747,6 +749,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         // (the operand loaded straight into registers, one tile ahead) stay in that XCD's L2
         g.m_fastest = ctx->knob[KN_X3_MFAST];
         if (o.grid_m_out) *o.grid_m_out = ceil_div(rows, 128);   // (in 128-row units whatever the tile)
+        g.xcd2d = ctx->knob[KN_X3_XCD2D];
         HIP_TRY(launch_gemm_pb(EPI_HALFSTEP, g, st));
         return KURBM_OK;
     }
@@ -939,6 +942,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.cfg = pl.cfg;
         g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
         g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
+        g.xcd2d = ctx->knob[KN_X3_XCD2D];
         HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
     }
     ReduceArgs a;
@@ -967,6 +971,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         // the fp32 master moves: the slab reduction writes the new weights AND their bf16 pieces in one launch
         a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
         a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = pieces;
+        a.tile_rows = ctx->knob[KN_REDUCE_TR];
         if (KURBM_STAGE(5)) HIP_TRY(launch_reduce_apply_split(a, st));
         if (only == 6)
             HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, pieces,
@@ -1078,6 +1083,7 @@ int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
     g.m_fastest = 1;
     g.bias = p->b_h;
     g.rowpart = reinterpret_cast<float*>(static_cast<char*>(workspace) + a_bytes);
+    g.xcd2d = ctx->knob[KN_X3_XCD2D];
     HIP_TRY(launch_gemm_pb(EPI_SOFTPLUS, g, st));
     FinishArgs f;
     f.v = v; f.b_v = p->b_v; f.rowpart = g.rowpart; f.F = F;
@@ -1209,6 +1215,7 @@ int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
     a.part_v = delta + nw + p->n_hid; a.nrow_tiles_v = 1; a.ld_part_v = p->n_vis; a.b_v = (which & 4) ? p->b_v : nullptr;
     a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
     a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = 3;
+    a.tile_rows = ctx->knob[KN_REDUCE_TR];
     HIP_TRY(launch_reduce_apply_split(a, st));
     return KURBM_OK;
 }

@@ -115,18 +115,25 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
 // ------------------------------------------------------------------------------------
 // slab reduction + parameter update + weight-piece mirror in ONE launch (x3 / bf16 steps)
 // ------------------------------------------------------------------------------------
-// Blocks [0, tiles): a TR x 64 tile of W each (TR = 16 / 32 / 64) -- sum the split-K slabs in index order (bit-reproducible), W += lr * dW
+// The first `nbias` blocks: the bias column sums (kurbm_kernels.h: bias_colsum_block; first, so that they do not trail the
+// launch).  Then `tiles` blocks, a TR x 64 tile of W each (TR = 16 / 32 / 64) -- sum the split-K slabs in index order (bit-reproducible), W += lr * dW
 // (and / or emit dW), then write the NEW weights as bf16 pieces row-major (8-byte stores) and, through an LDS transpose,
-// transposed; the k padding of both mirrors is rewritten as zeros.  Remaining blocks: the bias column sums of
-// k_reduce_apply (kurbm_kernels.hip).  Replaces k_reduce_apply + k_f32_to_bf16 on the fp32 master (one launch, one
+// transposed; the k padding of both mirrors is rewritten as zeros.  Replaces k_reduce_apply + k_f32_to_bf16 on the fp32 master (one launch, one
 // pass over W instead of three).
 template <int TR>
-__global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int tiles_x, int tiles) {
-    __shared__ float tile[TR][CVT + 1];
+__global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int tiles_x, int tiles, int nbias) {
+    __shared__ __attribute__((aligned(16))) float tile[TR][CVT + 1];
+    static_assert(sizeof(float) * TR * (CVT + 1) >= sizeof(double) * 8 * BIAS_COLS, "the bias blocks' scratch");
     const int t = threadIdx.x;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    if ((int)blockIdx.x < tiles) {
-        const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    // the first nbias blocks: bias column sums (kurbm_kernels.h); then the tiles of W
+    if ((int)blockIdx.x < nbias) {
+        bias_colsum_block(a, blockIdx.x, t, reinterpret_cast<double*>(&tile[0][0]));
+        return;
+    }
+    const int tb = (int)blockIdx.x - nbias;
+    if (tb < tiles) {
+        const int by = tb / tiles_x, bx = tb - by * tiles_x;
         const int q4 = (t & 15) * 4, rq = t >> 4;
         const int c = bx * CVT + q4;
         auto store3 = [&](uint16_t* dst, size_t plane, float v0, float v1, float v2, float v3) {
@@ -194,36 +201,6 @@ __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int ti
         }
         return;
     }
-    // bias partials [row tiles][columns] -> column sums: eight loads in flight per lane, fixed order
-    const int q = ((int)blockIdx.x - tiles) * 256 + t;
-    // in double: the rows are +sum(h_pos) ... -sum(h_neg) per 64 batch rows, two large totals that cancel
-    // (part2: n2 more rows that follow the n1 rows of part as if they were contiguous -- same additions, same order)
-    auto colsum = [](const float* __restrict__ part, int n1, int ld, int col, const float* __restrict__ part2 = nullptr, int n2 = 0) {
-        const int ntiles = n1 + (part2 ? n2 : 0);
-        auto at = [&](int i) { return (double)(i < n1 ? part[(size_t)i * ld + col] : part2[(size_t)(i - n1) * ld + col]); };
-        double u[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
-        int i = 0;
-        for (; i + 8 <= ntiles; i += 8) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) u[e] += at(i + e);
-        }
-        for (; i < ntiles; ++i) u[0] += at(i);
-        return (float)(((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7])));
-    };
-    if (q < a.n_hid) {
-        if (a.part_h) {
-            const float v = colsum(a.part_h, a.nrow_tiles_h, a.ld_part_h, q);
-            if (a.delta_bh) a.delta_bh[q] = v;
-            if (a.b_h) a.b_h[q] += a.lr * v;
-        }
-    } else if (q < a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis)) {
-        const int col = q - a.n_hid;
-        if (a.part_v) {
-            const float v = colsum(a.part_v, a.nrow_tiles_v, a.ld_part_v, col, a.part_v2, a.nrow_tiles_v2);
-            if (a.delta_bv) a.delta_bv[col] = v;
-            if (a.b_v) a.b_v[col] += a.lr * v;
-        }
-    }
 }
 
 // flag |= 1 if some element of `in` is not exactly representable in bf16, |= 2 if some element is neither 0.0 nor 1.0
@@ -279,16 +256,16 @@ hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st) {
     int r_ext = a.n_vis, c_ext = a.n_hid;
     if (a.Wb && a.ldWb > c_ext) c_ext = a.ldWb;
     if (a.Wtb && a.ldWtb > r_ext) r_ext = a.ldWtb;
-    const int nb = (a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis) + 255) / 256;
+    const int nb = bias_blocks(a);
     const int tiles_x = (c_ext + CVT - 1) / CVT;
     // taller tiles = longer runs in the transposed mirror (2 TR bytes per column) but fewer workgroups
-    static const int forced = getenv("KURBM_REDUCE_TR") ? atoi(getenv("KURBM_REDUCE_TR")) : 0;
+    const int forced = (a.tile_rows == 16 || a.tile_rows == 32 || a.tile_rows == 64) ? a.tile_rows : 0;
     int tr = forced ? forced : (tiles_x * ((r_ext + 31) / 32) >= 384 ? 32 : 16);
     const int tiles_y = (r_ext + tr - 1) / tr;
     const dim3 grid(tiles_x * tiles_y + nb);
-    if (tr == 64) hipLaunchKernelGGL(k_reduce_apply_split<64>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y);
-    else if (tr == 32) hipLaunchKernelGGL(k_reduce_apply_split<32>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y);
-    else hipLaunchKernelGGL(k_reduce_apply_split<16>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y);
+    if (tr == 64) hipLaunchKernelGGL(k_reduce_apply_split<64>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb);
+    else if (tr == 32) hipLaunchKernelGGL(k_reduce_apply_split<32>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb);
+    else hipLaunchKernelGGL(k_reduce_apply_split<16>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb);
     return hipGetLastError();
 }
 

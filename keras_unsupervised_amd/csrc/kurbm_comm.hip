@@ -5,9 +5,19 @@
 // RCCL is bound at run time (dlopen of the soname librccl.so.1, so a host process that already carries an RCCL --
 // a PyTorch process does -- shares that one instance; KURBM_RCCL_LIB names another file), never at link time:
 // the single-GPU library has no RCCL dependency and loads on a machine without it.
+//
+// The handful of RCCL types and constants this file needs are declared here, as rccl.h (2.x) declares them, so that the
+// library BUILDS without the RCCL headers too; the functions themselves come from dlsym.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;          // NCCL_UNIQUE_ID_BYTES
+typedef enum { ncclSuccess = 0 } ncclResult_t;                // (any other value: passed to ncclGetErrorString)
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+}
 
 #include <cstdlib>
 #include <cstring>
@@ -122,14 +132,23 @@ int kurbm_comm_init_rank(int device, int nranks, int rank, const void* id, size_
     if (R->error) return fail_msg(KURBM_ERR_COMM, "%s", R->error);
     if (!id || id_bytes < sizeof(ncclUniqueId)) return fail_msg(KURBM_ERR_ARG, "id must hold %zu bytes", sizeof(ncclUniqueId));
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail_msg(KURBM_ERR_ARG, "rank %d of %d", rank, nranks);
+    // (the caller's current device is restored on every path, as kurbm_comm_init_all and kurbm_comm_destroy do)
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
     HIP_TRY(hipSetDevice(device));
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     ncclComm_t nc = nullptr;
-    RCCL_TRY(R, R->CommInitRank(&nc, nranks, u, rank));
+    const ncclResult_t r = R->CommInitRank(&nc, nranks, u, rank);
+    if (r != ncclSuccess) {
+        (void)hipSetDevice(prev);
+        return fail_msg(KURBM_ERR_COMM, "ncclCommInitRank: %s", R->GetErrorString(r));
+    }
     kurbm_comm* c = new kurbm_comm;
     c->nccl = nc; c->device = device; c->nranks = nranks; c->rank = rank;
-    if (int e = finish_comm(c)) { kurbm_comm_destroy(c); return e; }
+    const int e = finish_comm(c);
+    (void)hipSetDevice(prev);
+    if (e) { kurbm_comm_destroy(c); return e; }
     *out = c;
     return KURBM_OK;
 }

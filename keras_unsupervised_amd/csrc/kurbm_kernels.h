@@ -90,8 +90,56 @@ struct ReduceArgs {
     uint16_t* Wb;         // [pieces][n_vis][ldWb]   nullable
     uint16_t* Wtb;        // [pieces][n_hid][ldWtb]
     int ldWb, ldWtb, pieces;
+    int tile_rows;        // k_reduce_apply_split: forced tile height 16 / 32 / 64 (ctx knob KURBM_REDUCE_TR); 0 = by the grid it makes
     size_t planeWb, planeWtb;
 };
+
+// Bias partials [row tiles][columns] -> column sums (k_reduce_apply, k_reduce_apply_split): blocks of BIAS_COLS columns x 8 row
+// groups.  A column's rows are spread over 8 threads, each with up to 8 loads in flight per pass (one thread per column
+// walked 128 rows of partials in 16 dependent passes of ~0.6 us: the longest chain of the whole launch, and it began last);
+// group sums and their total in double, in a fixed order: bit-reproducible.  Callers place these blocks FIRST in the grid.
+constexpr int BIAS_COLS = 32;
+static inline int bias_blocks(const ReduceArgs& a) { return (a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis) + BIAS_COLS - 1) / BIAS_COLS; }
+#if defined(__HIPCC__)
+__device__ __forceinline__ void bias_colsum_block(const ReduceArgs& a, int blk, int t, double* sh /* [8][BIAS_COLS] */) {
+    const int cl = t & (BIAS_COLS - 1), rg = t / BIAS_COLS;          // 256 threads: 8 row groups
+    const int q = blk * BIAS_COLS + cl;
+    const int nvb = a.n_vis_bias ? a.n_vis_bias : a.n_vis;
+    const bool hid = q < a.n_hid, vis = !hid && q < a.n_hid + nvb;
+    const float* part = hid ? a.part_h : (vis ? a.part_v : nullptr);
+    const float* part2 = vis ? a.part_v2 : nullptr;
+    const int n1 = hid ? a.nrow_tiles_h : a.nrow_tiles_v, n2 = part2 ? a.nrow_tiles_v2 : 0;
+    const int ld = hid ? a.ld_part_h : a.ld_part_v, col = hid ? q : q - a.n_hid;
+    double u = 0.;
+    if (part) {
+        const int ntiles = n1 + n2;
+        for (int j0 = 0; j0 < ntiles; j0 += 64) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = j0 + rg + 8 * e;
+                x[e] = (i < ntiles) ? (i < n1 ? part[(size_t)i * ld + col] : part2[(size_t)(i - n1) * ld + col]) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u += (double)x[e];
+        }
+    }
+    sh[rg * BIAS_COLS + cl] = u;
+    __syncthreads();
+    if (t < BIAS_COLS && part) {
+        const double* s = sh + t;
+        const float v = (float)(((s[0] + s[BIAS_COLS]) + (s[2 * BIAS_COLS] + s[3 * BIAS_COLS])) +
+                                ((s[4 * BIAS_COLS] + s[5 * BIAS_COLS]) + (s[6 * BIAS_COLS] + s[7 * BIAS_COLS])));
+        if (hid) {
+            if (a.delta_bh) a.delta_bh[col] = v;
+            if (a.b_h) a.b_h[col] += a.lr * v;
+        } else {
+            if (a.delta_bv) a.delta_bv[col] = v;
+            if (a.b_v) a.b_v[col] += a.lr * v;
+        }
+    }
+}
+#endif
 
 struct ApplyArgs {
     const float* delta;
@@ -182,6 +230,7 @@ struct GemmArgsB {
     // (8 / (xcd_r xcd_c)) x xcd_r x xcd_c grid over (k slices, row tiles, column tiles); each takes one block of it, so the A
     // rows and B rows it pulls through its own L2 are a fraction of the matrix instead of all of one operand
     int xcd_r, xcd_c;
+    int xcd2d;            // caller: 1 = let the launcher pick such blocks (ctx knob KURBM_X3_XCD2D), 0 = the linear order
     // softplus epilogue (k_gemm_pb, free energy): rowpart[bn][row] = sum over the tile's columns of softplus(x + bias)
     float* rowpart;
     int ld_rowpart;

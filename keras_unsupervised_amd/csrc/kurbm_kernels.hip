@@ -593,15 +593,22 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
 // ------------------------------------------------------------------------------------
 // slab reduction (+ parameter update)
 // ------------------------------------------------------------------------------------
-// Blocks [0, nblk_w) sum the split-K slabs of dW (4 columns per thread) and either add
-// lr * dW into W or store dW densely; the blocks after them reduce the bias partials.
-__global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
+// The first nbias8 blocks (nbias rounded up to 8, so that the blocks behind keep their XCD) reduce the bias partials
+// (kurbm_kernels.h: bias_colsum_block); the nblk_w blocks after them sum the split-K slabs of dW (4 columns per thread) and
+// either add lr * dW into W or store dW densely.
+__global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a, int nbias, int nbias8) {
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < a.nblk_w) {
+    if ((int)blockIdx.x < nbias8) {
+        __shared__ double sh[8 * BIAS_COLS];
+        if ((int)blockIdx.x < nbias) bias_colsum_block(a, blockIdx.x, tid, sh);
+        return;
+    }
+    const int blk = (int)blockIdx.x - nbias8;
+    if (blk < a.nblk_w) {
         if (a.tile_bm > 0) {
             // tile order: the same XCD remap as the GEMM, then (tile, part of the tile)
             const int nwg = a.nblk_w;
-            int bid = blockIdx.x;
+            int bid = blk;
             const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
             bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
             const int tile = bid / a.parts, part = bid - tile * a.parts;
@@ -647,9 +654,9 @@ __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
             return;
         }
     }
-    if ((int)blockIdx.x < a.nblk_w) {   // row order (no tile geometry given)
+    if (blk < a.nblk_w) {   // row order (no tile geometry given)
         const int groups = a.ld_slab / 4;  // float4 groups per row
-        const long long q = (long long)blockIdx.x * 256 + tid;
+        const long long q = (long long)blk * 256 + tid;
         if (q >= (long long)a.n_vis * groups) return;
         const int i = (int)(q / groups), j0 = (int)(q - (long long)i * groups) * 4;
         // slabs are summed in index order (bit-reproducible); four loads in flight per lane
@@ -685,38 +692,6 @@ __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a) {
             }
         }
         return;
-    }
-    // bias partials [row tiles][columns] -> column sums: eight loads in flight per lane, partial sums
-    // combined in a fixed order (bit-reproducible)
-    const int q = ((int)blockIdx.x - a.nblk_w) * 256 + tid;
-    // accumulated in double: on the x3 path the rows are +sum(h_pos) ... -sum(h_neg) per 64 batch rows, two large
-    // totals that cancel, and an fp32 running sum would lose ~1e-4 of the difference
-    // (part2: n2 more rows that follow the n1 rows of part as if they were contiguous -- same additions, same order)
-    auto colsum = [](const float* __restrict__ part, int n1, int ld, int c, const float* __restrict__ part2 = nullptr, int n2 = 0) {
-        const int ntiles = n1 + (part2 ? n2 : 0);
-        auto at = [&](int r) { return (double)(r < n1 ? part[(size_t)r * ld + c] : part2[(size_t)(r - n1) * ld + c]); };
-        double t[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
-        int r = 0;
-        for (; r + 8 <= ntiles; r += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] += at(r + u);
-        }
-        for (; r < ntiles; ++r) t[0] += at(r);
-        return (float)(((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])));
-    };
-    if (q < a.n_hid) {
-        if (a.part_h) {
-            const float t = colsum(a.part_h, a.nrow_tiles_h, a.ld_part_h, q);
-            if (a.delta_bh) a.delta_bh[q] = t;
-            if (a.b_h) a.b_h[q] += a.lr * t;
-        }
-    } else if (q < a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis)) {
-        const int c = q - a.n_hid;
-        if (a.part_v) {
-            const float t = colsum(a.part_v, a.nrow_tiles_v, a.ld_part_v, c, a.part_v2, a.nrow_tiles_v2);
-            if (a.delta_bv) a.delta_bv[c] = t;
-            if (a.b_v) a.b_v[c] += a.lr * t;
-        }
     }
 }
 
@@ -810,8 +785,8 @@ hipError_t launch_philox_uniform(float* out, int rows, int cols, int ld, const R
 }
 
 hipError_t launch_reduce_apply(const ReduceArgs& a, hipStream_t st) {
-    const int nb = (a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis) + 255) / 256;
-    hipLaunchKernelGGL(k_reduce_apply, dim3(a.nblk_w + nb), dim3(256), 0, st, a);
+    const int nb = bias_blocks(a), nb8 = (nb + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_reduce_apply, dim3(a.nblk_w + nb8), dim3(256), 0, st, a, nb, nb8);
     return hipGetLastError();
 }
 

@@ -976,8 +976,7 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     {   // XCD blocks: the factorisation 8 = xz * xr * xc (xz | nsplit, xr | grid_m, xc | grid_n) with the fewest operand rows
         // per XCD, weighted by the tiles a k-tile loads (one A tile per segment, npb B tiles)
         g.xcd_r = g.xcd_c = 0;
-        static const int on = getenv("KURBM_X3_XCD2D") ? atoi(getenv("KURBM_X3_XCD2D")) : 1;
-        if (on && nblk % 8 == 0) {
+        if (g.xcd2d && nblk % 8 == 0) {
             int wa = 0, wb = 0;
             for (int sgm = 0; sgm < g.nseg; ++sgm) { wa += 1; wb += (int)((g.seg_codes >> (5 * sgm + 2)) & 3u); }
             const int bmr = (g.cfg == 2) ? 256 : 128, bnr = (g.cfg == 2) ? 64 : 128;
