@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define KURBM_ABI_VERSION 3
+#define KURBM_ABI_VERSION 4
 
 typedef struct kurbm_ctx kurbm_ctx;
 typedef struct kurbm_comm kurbm_comm; /* one RCCL communicator + the library's comm stream and events, per GPU */
@@ -116,6 +116,12 @@ void kurbm_ctx_destroy(kurbm_ctx* ctx);
  * environment once, in kurbm_ctx_create; this sets one of them (by its environment name, e.g. "KURBM_X3_TALL") on a
  * live context.  -1 = automatic where a knob has an automatic setting.  No production caller needs it. */
 int kurbm_ctx_set_option(kurbm_ctx* ctx, const char* name, int value);
+/* Sticky status bits of the context's kernels, read back from the device (THIS call synchronises with the device; the
+ * others never do) and cleared.  Bit 0: a workgroup of the statistics GEMM of kurbm_cd_step_x3 / _bf16 -- which reduces
+ * its own split-K slabs when its whole grid is resident, one workgroup per CU -- gave up waiting for the other k-slices of
+ * its tile (0.2 s), i.e. the grid was NOT resident (a CU mask, a device shared with a kernel that never ends): that
+ * step's update of W is incomplete.  0 in every run this build has seen; set KURBM_X3_FUSED=0 where it is not. */
+int kurbm_ctx_status(kurbm_ctx* ctx, int* bits);
 
 /* ---- RNG test hook: out[r, c] = u(row0 + r, c) under the contract above -------- */
 int kurbm_philox_uniform(kurbm_ctx* ctx, float* out, int rows, int cols, int ld,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "kurbm_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "kurbm_ctx_destroy": (None, [_vp]),
     "kurbm_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "kurbm_ctx_status": (_i, [_vp, C.POINTER(_i)]),
     "kurbm_philox_uniform": (_i, [_vp, _vp, _i, _i, _i, _RP, _vp]),
     "kurbm_half_step_vh": (_i, [_vp, _PP, _vp, _i, _i, _i, _i, _RP, _vp, _vp, _i, _vp]),
     "kurbm_half_step_hv": (_i, [_vp, _PP, _vp, _i, _i, _i, _i, _RP, _vp, _vp, _i, _vp]),
@@ -88,7 +89,7 @@ SIGNATURES = {
     "kurbm_cd_step_x3_dp": (_i, [_vp, _vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _vp, _sz, _vp]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 V_BINARY = 0x10          # KURBM_V_BINARY: OR into v_pieces = 1 for 0/1 data
 UNIQUE_ID_BYTES = 128
 
@@ -105,12 +106,21 @@ def load():
             "HIP library %s is missing; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C keras_unsupervised_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
-        fn.restype, fn.argtypes = res, args
-    if lib.kurbm_abi_version() != ABI_VERSION:
+    # the ABI guard FIRST: a stale build lacks the newer symbols, and a bare AttributeError would say nothing about rebuilding
+    ver = getattr(lib, "kurbm_abi_version", None)
+    if ver is None:
+        raise KurbmError("%s does not export kurbm_abi_version: not a libkurbm build; rebuild it "
+                         "(make -C keras_unsupervised_amd/csrc)" % LIB_PATH)
+    ver.restype, ver.argtypes = SIGNATURES["kurbm_abi_version"]
+    if ver() != ABI_VERSION:
         raise KurbmError("%s implements ABI %d, this package binds ABI %d: rebuild it (make -C keras_unsupervised_amd/csrc)"
-                         % (LIB_PATH, lib.kurbm_abi_version(), ABI_VERSION))
+                         % (LIB_PATH, ver(), ABI_VERSION))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise KurbmError("%s (ABI %d) does not export %s: rebuild it (make -C keras_unsupervised_amd/csrc)"
+                             % (LIB_PATH, ABI_VERSION, name))
+        fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
 
@@ -133,6 +143,13 @@ class Context:
         self.handle = h
         self.device_index = int(device_index)
         self.lib = lib
+
+    def status(self):
+        """Sticky status bits of the context's kernels, read back and cleared (synchronises with the device): bit 0 = a
+        fused statistics launch found its grid not resident and left W alone (include/kurbm.h: kurbm_ctx_status)."""
+        bits = _i(0)
+        check(self.lib.kurbm_ctx_status(self.handle, C.byref(bits)))
+        return int(bits.value)
 
     def set_option(self, name, value):
         """Set one experiment knob (its KURBM_* environment name) on this context; -1 = automatic."""

@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_COUNT };
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
@@ -35,6 +35,8 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_UNFUSED_MIRROR", 0},   // 1: slab reduce and weight-piece mirror as two launches
     {"KURBM_X3_XCD2D", 1},         // 0: linear block order of k_gemm_pb instead of one 2-D block of tiles per XCD
     {"KURBM_REDUCE_TR", 0},        // tile height (16 / 32 / 64) of the slab-reduce + mirror launch; 0: by the grid it makes
+    {"KURBM_X3_FUSED", 0},         // 1: the statistics GEMM reduces its own split-K slabs where its grid is resident (bit-identical to the
+                                   //    separate reduce launch and no faster: 117.7 against 117.5 us per step)
 };
 
 struct kurbm_ctx {
@@ -45,6 +47,7 @@ struct kurbm_ctx {
     int force_split;    // KURBM_SPLIT
     int tile_major;     // KURBM_TILE_MAJOR (default 1): k-slices of a statistics tile share an XCD
     int knob[KN_COUNT];
+    unsigned* status;   // device word, sticky: kurbm_ctx_status (the only device memory the library owns: 256 bytes)
 };
 
 static int env_int(const char* name, int dflt) {
@@ -281,7 +284,30 @@ int kurbm_ctx_create(int device, kurbm_ctx** out) {
     c->force_split = env_int("KURBM_SPLIT", -1);
     c->tile_major = env_int("KURBM_TILE_MAJOR", 1);
     for (int i = 0; i < KN_COUNT; ++i) c->knob[i] = env_int(KNOBS[i].env, KNOBS[i].dflt);
+    c->status = nullptr;
+    {
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->status), 256);
+        if (e == hipSuccess) e = hipMemset(c->status, 0, 256);
+        (void)hipSetDevice(prev);
+        if (e != hipSuccess) {
+            if (c->status) (void)hipFree(c->status);
+            delete c;
+            return fail(KURBM_ERR_HIP, "status word of the context: %s", hipGetErrorString(e));
+        }
+    }
     *out = c;
+    return KURBM_OK;
+}
+
+int kurbm_ctx_status(kurbm_ctx* ctx, int* bits) {
+    if (!ctx || !bits) return fail(KURBM_ERR_ARG, "null argument");
+    unsigned v = 0;
+    HIP_TRY(hipMemcpy(&v, ctx->status, sizeof v, hipMemcpyDeviceToHost));      // (synchronises with the device)
+    if (v) HIP_TRY(hipMemset(ctx->status, 0, sizeof v));
+    *bits = (int)v;
     return KURBM_OK;
 }
 
@@ -299,6 +325,7 @@ int kurbm_ctx_set_option(kurbm_ctx* ctx, const char* name, int value) {
 
 void kurbm_ctx_destroy(kurbm_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->status) (void)hipFree(ctx->status);
     delete ctx;
 }
 
@@ -590,12 +617,14 @@ static Mirror carve_mirror(const kurbm_ctx* ctx, void* base, int n_vis, int n_hi
 struct WorkspaceB {
     uint16_t *vb, *vbT, *hb, *hbT, *v2b, *v2bT, *h2b, *hnT, *cb;
     float *part_h, *part_v, *slab, *tmp32;
+    unsigned* sync;     // SYNC_WORDS arrival counters of the fused slab reduction (one per output tile of the statistics)
     int Kv, Kh, Kb, Lv, Lh, Lb, ldh32, ldv32, max_row_tiles;   // K*: k extents; L*: leading dimensions of the bf16 planes
     size_t planeV, planeVT, planeHT;   // distance between the pieces of v_pos (both images) and of h_neg^T
     size_t slab_stride, bytes;
 };
 
 struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_split, ld_slab, cfg; };
+constexpr int SYNC_WORDS = 1024;   // >= the CUs of any gfx950 part: a fused statistics grid has at most one tile per CU
 
 // the statistics GEMM on k_gemm_pb: k-tile 64, one workgroup per CU, nseg segments walked fastest, so a slice is a whole
 // number of k positions
@@ -668,6 +697,7 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.part_v = take32((size_t)(ceil_div(rows, 64) + 2 * w.max_row_tiles) * w.ldv32);
     w.slab = take32(w.slab_stride * pl.nsplit_bound);
     w.tmp32 = take32((size_t)rows * (w.ldh32 > w.ldv32 ? w.ldh32 : w.ldv32));       // fp32 plane for the test hook
+    w.sync = reinterpret_cast<unsigned*>(take32(SYNC_WORDS));
     w.bytes = off;
     return w;
 }
@@ -705,6 +735,7 @@ struct HalfOutB {
     float* colpart = nullptr; int ld_colpart = 0;
     float colsign = 1.f;                                  // x3: colpart = colsign * column sums of the value plane
     int* grid_m_out = nullptr;
+    unsigned* zero_words = nullptr; int n_zero = 0;       // words this launch zeroes (the next launch's arrival counters)
 };
 
 // one half step: A [rows][lda] bf16 in a_pieces pieces (k padded), weights from the mirror
@@ -745,6 +776,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.outT_neg = o.outT_neg ? 1 : 0; g.outT_f8 = o.outT_f8 ? 1 : 0;
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
         g.colpart = o.colpart; g.ld_colpart = o.ld_colpart; g.colsign = o.colsign;
+        g.zero_words = o.zero_words; g.n_zero = o.n_zero;
         // row tiles fastest: an XCD's run of workgroups then shares ONE column tile, whose weight pieces
         // (the operand loaded straight into registers, one tile ahead) stay in that XCD's L2
         g.m_fastest = ctx->knob[KN_X3_MFAST];
@@ -801,6 +833,33 @@ static int half_step_any(kurbm_ctx* ctx, int pieces, int in_pieces, const kurbm_
                        rng ? &r : nullptr, o, st);
 }
 
+// Every argument check of a bf16 / x3 CD step, before anything is enqueued.  The data-parallel step runs it BEFORE its first
+// collective too: a rank that fails here returns without having joined an all-reduce, and so must every other rank -- the
+// checks depend only on arguments that are the same on all ranks (shapes, options, buffer sizes), except `rows`, which a rank
+// may have none of (zero_rows_ok).
+static int check_cd_args(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_params* p, const void* mirror, size_t mirror_bytes,
+                         const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o, const void* workspace,
+                         size_t workspace_bytes, bool zero_rows_ok) {
+    if (!ctx || !o) return fail(KURBM_ERR_ARG, "null argument");
+    if (int e = check_params(p)) return e;
+    if (rows < 0 || (rows == 0 && !zero_rows_ok)) return fail(KURBM_ERR_ARG, "rows must be positive");
+    if (rows > 0 && bad_matrix(v_batch, ldv, p->n_vis)) return fail(KURBM_ERR_ARG, "v_batch: null, misaligned, ld %% 4 != 0 or ld < n_vis");
+    if (o->k < 1 || o->k > 15) return fail(KURBM_ERR_ARG, "k must be in [1, 15]");
+    if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN)
+        return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
+    if (v_pieces == (1 | KURBM_V_BINARY)) v_pieces = 1;
+    if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1, 1 | KURBM_V_BINARY or 3");
+    if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
+    if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
+    if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
+    if (o->v_planes && !aligned16(o->v_planes)) return fail(KURBM_ERR_ARG, "v_planes is misaligned");
+    const size_t mb = carve_mirror(ctx, nullptr, p->n_vis, p->n_hid, pieces).bytes;
+    if (mb > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", mb, mirror_bytes);
+    const size_t wb = carve_bf16(ctx, nullptr, rows > 0 ? rows : 1, p->n_vis, p->n_hid, pieces, v_pieces).bytes;
+    if (wb > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", wb, workspace_bytes);
+    return KURBM_OK;
+}
+
 static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                        const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace,
                        size_t workspace_bytes, kurbm_stream_t stream, int only = -1, int m_lo = 0, int m_hi = -1) {
@@ -810,24 +869,12 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     // all-reduces the first rows of dW while the rest is still being computed.
 #define KURBM_STAGE(n) (only < 0 || only == (n) || (only == 8 && (n) <= 3) || (only == 7 && ((n) == 4 || (n) == 5)))
     if (m_hi < 0) m_hi = p ? p->n_vis : 0;
-    if (!ctx || !o) return fail(KURBM_ERR_ARG, "null argument");
-    if (int e = check_params(p)) return e;
-    if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
-    if (bad_matrix(v_batch, ldv, p->n_vis)) return fail(KURBM_ERR_ARG, "v_batch: null, misaligned, ld %% 4 != 0 or ld < n_vis");
-    if (o->k < 1 || o->k > 15) return fail(KURBM_ERR_ARG, "k must be in [1, 15]");
-    if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN)
-        return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
+    if (int e = check_cd_args(ctx, pieces, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, workspace, workspace_bytes, false)) return e;
     const bool v_binary = (v_pieces == (1 | KURBM_V_BINARY));
     if (v_binary) v_pieces = 1;
-    if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1, 1 | KURBM_V_BINARY or 3");
-    if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
-    if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
-    if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, pieces);
-    if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
     WorkspaceB w = carve_bf16(ctx, workspace, rows, p->n_vis, p->n_hid, pieces, v_pieces);
-    if (w.bytes > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
 
     const bool gauss = (o->mode == KURBM_MODE_VISIBLE_GAUSSIAN);
     const int act_h = gauss ? ACT_RELU : ACT_SIGMOID;
@@ -901,16 +948,6 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             h_cur = w.h2b;
         }
     }
-    // h_neg = sigmoid(v_neg.W + b_h), probabilities (rbm.py:124): only its transposed image is needed, and only by the
-    // statistics GEMM, where it enters with a minus sign: it is stored as -h_neg
-    if (KURBM_STAGE(3)) {
-        HalfOutB ho;
-        ho.outT = w.hnT; ho.ldoT = w.Lb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT; ho.outT_neg = true;
-        ho.colpart = w.part_h + (size_t)2 * ceil_div(rows, 128) * w.ldh32; ho.ld_colpart = w.ldh32; ho.colsign = -1.f;
-        ho.grid_m_out = &gm_h;
-        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st, nbytes))) return e;
-    }
-
     // dW = v_pos^T.h_pos - v_neg^T.h_neg: NT GEMM over the transposed images, k = batch;
     // segments: (piece of v_pos) x h_pos, then v_neg x (piece of -h_neg)
     const int nseg_st = pieces == 3 ? v_pieces + vn_pieces : 2;
@@ -922,7 +959,54 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
                                                 (int)((w.slab_stride * plf.nsplit_bound) / ((size_t)Mr * plf.ld_slab)), f8pos, pieces == 3)
                               : plf;
     const size_t slab_stride = sub ? (size_t)Mr * pl.ld_slab : w.slab_stride;
+    const bool ap = o->apply != 0;
+    // FUSED reduction: the statistics GEMM sums its own split-K slabs, applies lr * dW and rewrites the weight-piece mirror
+    // (kurbm_x3.hip) -- no k_reduce_apply_split launch.  Only where every workgroup of its grid is resident at once (one
+    // per CU: the k-slices of a tile wait for each other) and the step applies its update in place; the data-parallel,
+    // emit-only, row-range and `which`-restricted forms keep the separate launch.
+    const bool fuse = ctx->knob[KN_X3_FUSED] != 0 && !ctx->knob[KN_UNFUSED_MIRROR] && need_w && ap && (which & 1) && !o->delta_out &&
+                      !sub && (only < 0 || only == 4) && pl.gm * pl.gn * pl.nsplit <= ctx->ncu && pl.gm * pl.gn <= SYNC_WORDS &&
+                      (size_t)pl.nsplit * slab_stride * 4 < 0x7FFFFFFFull;
+    // h_neg = sigmoid(v_neg.W + b_h), probabilities (rbm.py:124): only its transposed image is needed, and only by the
+    // statistics GEMM, where it enters with a minus sign: it is stored as -h_neg
+    if (KURBM_STAGE(3)) {
+        HalfOutB ho;
+        if (fuse) { ho.zero_words = w.sync; ho.n_zero = pl.gm * pl.gn; }   // (the arrival counters of the launch that follows)
+        ho.outT = w.hnT; ho.ldoT = w.Lb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT; ho.outT_neg = true;
+        ho.colpart = w.part_h + (size_t)2 * ceil_div(rows, 128) * w.ldh32; ho.ld_colpart = w.ldh32; ho.colsign = -1.f;
+        ho.grid_m_out = &gm_h;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st, nbytes))) return e;
+    }
+
     int nslab_used = pl.nsplit;
+    ReduceArgs a;
+    memset(&a, 0, sizeof a);
+    a.slab = w.slab; a.slab_stride = slab_stride; a.ld_slab = pl.ld_slab;
+    a.nslab = nslab_used;
+    a.n_vis = Mr; a.n_hid = p->n_hid; a.ldw = p->ldw;
+    a.nblk_w = need_w ? (int)(((long long)Mr * (pl.ld_slab / 4) + 255) / 256) : 0;
+    a.lr = o->lr;
+    a.W = (ap && (which & 1)) ? p->W : nullptr;
+    a.delta_w = o->delta_out ? o->delta_out + (size_t)m_lo * p->n_hid : nullptr;
+    a.part_h = w.part_h; a.nrow_tiles_h = 4 * gm_h; a.ld_part_h = w.ldh32;
+    a.b_h = (ap && (which & 2)) ? p->b_h : nullptr;
+    a.delta_bh = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid : nullptr;
+    a.part_v = w.part_v; a.nrow_tiles_v = gp_v + 2 * gm_v; a.ld_part_v = w.ldv32;
+    if (part_v_pos) {   // rows [0, gp_v) from the resident planes, then the workspace's negative rows
+        a.part_v = part_v_pos; a.nrow_tiles_v = gp_v;
+        a.part_v2 = w.part_v + (size_t)gp_v * w.ldv32; a.nrow_tiles_v2 = 2 * gm_v;
+    }
+    a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
+    a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
+    if (sub && m_hi != p->n_vis) { a.part_h = nullptr; a.part_v = nullptr; a.part_v2 = nullptr; }   // the bias sums leave with the LAST rows
+    if (sub) a.n_vis_bias = p->n_vis;
+    const bool mirror_in_reduce = a.W && need_w && !ctx->knob[KN_UNFUSED_MIRROR];
+    if (mirror_in_reduce) {
+        // the fp32 master moves: the slab reduction writes the new weights AND their bf16 pieces in one pass
+        a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
+        a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = pieces;
+        a.tile_rows = ctx->knob[KN_REDUCE_TR];
+    }
     if (need_w && KURBM_STAGE(4)) {
         GemmArgsB g;
         memset(&g, 0, sizeof g);
@@ -943,35 +1027,15 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
         g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
         g.xcd2d = ctx->knob[KN_X3_XCD2D];
+        if (fuse) {
+            g.fuse = 1; g.sync = w.sync; g.status = ctx->status; g.red = a;
+            // (a launch replayed alone, kurbm_cd_step_x3_stage: no half step in front has zeroed the counters)
+            if (only == 4) HIP_TRY(hipMemsetAsync(w.sync, 0, (size_t)pl.gm * pl.gn * sizeof(unsigned), st));
+        }
         HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
     }
-    ReduceArgs a;
-    memset(&a, 0, sizeof a);
-    a.slab = w.slab; a.slab_stride = slab_stride; a.ld_slab = pl.ld_slab;
-    a.nslab = nslab_used;
-    a.n_vis = Mr; a.n_hid = p->n_hid; a.ldw = p->ldw;
-    a.nblk_w = need_w ? (int)(((long long)Mr * (pl.ld_slab / 4) + 255) / 256) : 0;
-    a.lr = o->lr;
-    const bool ap = o->apply != 0;
-    a.W = (ap && (which & 1)) ? p->W : nullptr;
-    a.delta_w = o->delta_out ? o->delta_out + (size_t)m_lo * p->n_hid : nullptr;
-    a.part_h = w.part_h; a.nrow_tiles_h = 4 * gm_h; a.ld_part_h = w.ldh32;
-    a.b_h = (ap && (which & 2)) ? p->b_h : nullptr;
-    a.delta_bh = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid : nullptr;
-    a.part_v = w.part_v; a.nrow_tiles_v = gp_v + 2 * gm_v; a.ld_part_v = w.ldv32;
-    if (part_v_pos) {   // rows [0, gp_v) from the resident planes, then the workspace's negative rows
-        a.part_v = part_v_pos; a.nrow_tiles_v = gp_v;
-        a.part_v2 = w.part_v + (size_t)gp_v * w.ldv32; a.nrow_tiles_v2 = 2 * gm_v;
-    }
-    a.b_v = (ap && (which & 4)) ? p->b_v : nullptr;
-    a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
-    if (sub && m_hi != p->n_vis) { a.part_h = nullptr; a.part_v = nullptr; a.part_v2 = nullptr; }   // the bias sums leave with the LAST rows
-    if (sub) a.n_vis_bias = p->n_vis;
-    if (a.W && need_w && !ctx->knob[KN_UNFUSED_MIRROR]) {
-        // the fp32 master moves: the slab reduction writes the new weights AND their bf16 pieces in one launch
-        a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
-        a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = pieces;
-        a.tile_rows = ctx->knob[KN_REDUCE_TR];
+    if (fuse) return KURBM_OK;   // W, the biases and the mirror have been written by the statistics launch
+    if (mirror_in_reduce) {
         if (KURBM_STAGE(5)) HIP_TRY(launch_reduce_apply_split(a, st));
         if (only == 6)
             HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, pieces,
@@ -1139,6 +1203,9 @@ int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p,
     if (!opts->delta_out || !aligned16(opts->delta_out)) return fail(KURBM_ERR_ARG, "delta_out (the packed sums) is required, 16-byte aligned");
     if (comm->device != ctx->device) return fail(KURBM_ERR_ARG, "communicator is on device %d, context on %d", comm->device, ctx->device);
     if (rows < 0) return fail(KURBM_ERR_ARG, "rows must be >= 0");
+    // everything cd_step_any would refuse is refused HERE, before the first collective is enqueued: a rank that returned
+    // an error from inside the sequence would leave the other ranks waiting in ncclAllReduce
+    if (int e = check_cd_args(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, opts, workspace, workspace_bytes, true)) return e;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t nw = (size_t)p->n_vis * p->n_hid, ntot = nw + p->n_hid + p->n_vis;
     // row ranges of dW: boundaries on multiples of 128 (the statistics tile), the same on every rank

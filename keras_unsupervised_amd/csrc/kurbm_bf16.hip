@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
 // ------------------------------------------------------------------------------------
 // slab reduction + parameter update + weight-piece mirror in ONE launch (x3 / bf16 steps)
 // ------------------------------------------------------------------------------------
-// The first `nbias` blocks: the bias column sums (kurbm_kernels.h: bias_colsum_block; first, so that they do not trail the
+// The first `nbias` blocks: the bias column sums (kurbm_kernels.h: bias_colsum_wave; first, so that they do not trail the
 // launch).  Then `tiles` blocks, a TR x 64 tile of W each (TR = 16 / 32 / 64) -- sum the split-K slabs in index order (bit-reproducible), W += lr * dW
 // (and / or emit dW), then write the NEW weights as bf16 pieces row-major (8-byte stores) and, through an LDS transpose,
 // transposed; the k padding of both mirrors is rewritten as zeros.  Replaces k_reduce_apply + k_f32_to_bf16 on the fp32 master (one launch, one
@@ -123,12 +123,11 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
 template <int TR>
 __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int tiles_x, int tiles, int nbias) {
     __shared__ __attribute__((aligned(16))) float tile[TR][CVT + 1];
-    static_assert(sizeof(float) * TR * (CVT + 1) >= sizeof(double) * 8 * BIAS_COLS, "the bias blocks' scratch");
     const int t = threadIdx.x;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     // the first nbias blocks: bias column sums (kurbm_kernels.h); then the tiles of W
     if ((int)blockIdx.x < nbias) {
-        bias_colsum_block(a, blockIdx.x, t, reinterpret_cast<double*>(&tile[0][0]));
+        bias_colsum_wave(a, blockIdx.x * 4 + (t >> 6), t & 63);
         return;
     }
     const int tb = (int)blockIdx.x - nbias;

@@ -94,16 +94,19 @@ struct ReduceArgs {
     size_t planeWb, planeWtb;
 };
 
-// Bias partials [row tiles][columns] -> column sums (k_reduce_apply, k_reduce_apply_split): blocks of BIAS_COLS columns x 8 row
-// groups.  A column's rows are spread over 8 threads, each with up to 8 loads in flight per pass (one thread per column
-// walked 128 rows of partials in 16 dependent passes of ~0.6 us: the longest chain of the whole launch, and it began last);
-// group sums and their total in double, in a fixed order: bit-reproducible.  Callers place these blocks FIRST in the grid.
-constexpr int BIAS_COLS = 32;
-static inline int bias_blocks(const ReduceArgs& a) { return (a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis) + BIAS_COLS - 1) / BIAS_COLS; }
+// Bias partials [row tiles][columns] -> column sums (k_reduce_apply, k_reduce_apply_split, and the prologue of the statistics
+// GEMM when it reduces its own slabs): one WAVE per 8 columns, lane = 8 rg + column.  A column's rows are spread over 8 lanes
+// (row groups), each with up to 8 loads in flight per pass -- one thread per column walked 128 rows of partials in 16
+// dependent passes of ~0.6 us, the longest chain of the whole launch, and it began last.  Group sums and their total in
+// double, the total by an xor-shuffle tree ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7)): a fixed order, bit-reproducible,
+// no LDS and no barrier.  Callers place this work FIRST in their grid.
+constexpr int BIAS_COLS = 32;     // columns per 256-thread block (4 waves)
+__host__ __device__ static inline int bias_waves(const ReduceArgs& a) { return (a.n_hid + (a.n_vis_bias ? a.n_vis_bias : a.n_vis) + 7) / 8; }
+static inline int bias_blocks(const ReduceArgs& a) { return (bias_waves(a) + 3) / 4; }
 #if defined(__HIPCC__)
-__device__ __forceinline__ void bias_colsum_block(const ReduceArgs& a, int blk, int t, double* sh /* [8][BIAS_COLS] */) {
-    const int cl = t & (BIAS_COLS - 1), rg = t / BIAS_COLS;          // 256 threads: 8 row groups
-    const int q = blk * BIAS_COLS + cl;
+__device__ __forceinline__ void bias_colsum_wave(const ReduceArgs& a, int group, int lane) {
+    const int cl = lane & 7, rg = lane >> 3;
+    const int q = group * 8 + cl;
     const int nvb = a.n_vis_bias ? a.n_vis_bias : a.n_vis;
     const bool hid = q < a.n_hid, vis = !hid && q < a.n_hid + nvb;
     const float* part = hid ? a.part_h : (vis ? a.part_v : nullptr);
@@ -124,12 +127,11 @@ __device__ __forceinline__ void bias_colsum_block(const ReduceArgs& a, int blk, 
             for (int e = 0; e < 8; ++e) u += (double)x[e];
         }
     }
-    sh[rg * BIAS_COLS + cl] = u;
-    __syncthreads();
-    if (t < BIAS_COLS && part) {
-        const double* s = sh + t;
-        const float v = (float)(((s[0] + s[BIAS_COLS]) + (s[2 * BIAS_COLS] + s[3 * BIAS_COLS])) +
-                                ((s[4 * BIAS_COLS] + s[5 * BIAS_COLS]) + (s[6 * BIAS_COLS] + s[7 * BIAS_COLS])));
+    u += __shfl_xor(u, 8);
+    u += __shfl_xor(u, 16);
+    u += __shfl_xor(u, 32);
+    if (rg == 0 && part) {
+        const float v = (float)u;
         if (hid) {
             if (a.delta_bh) a.delta_bh[col] = v;
             if (a.b_h) a.b_h[col] += a.lr * v;
@@ -234,6 +236,17 @@ struct GemmArgsB {
     // softplus epilogue (k_gemm_pb, free energy): rowpart[bn][row] = sum over the tile's columns of softplus(x + bias)
     float* rowpart;
     int ld_rowpart;
+    // EPI_SLAB with fuse != 0: the statistics GEMM reduces its own split-K slabs (kurbm_x3.hip, "fused reduction"): `red`
+    // names W, lr, the weight-piece mirror and the bias partials exactly as the separate launch (k_reduce_apply_split) takes
+    // them; `sync` = one arrival counter per output tile [grid_m * grid_n], ZERO when the launch starts (the half step in
+    // front zeroes them: zero_words); `status` = a sticky word of the context, bit 0 set if a workgroup gave up waiting
+    int fuse;
+    unsigned* sync;
+    unsigned* status;
+    ReduceArgs red;
+    // EPI_HALFSTEP: workgroup 0 stores n_zero zeros here (the arrival counters of the statistics GEMM that follows)
+    unsigned* zero_words;
+    int n_zero;
     // diagnostic build only (KURBM_STAMPS): 8 x u64 per workgroup (k_gemm_pb)
     unsigned long long* stamps;
 };

@@ -594,13 +594,12 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
 // slab reduction (+ parameter update)
 // ------------------------------------------------------------------------------------
 // The first nbias8 blocks (nbias rounded up to 8, so that the blocks behind keep their XCD) reduce the bias partials
-// (kurbm_kernels.h: bias_colsum_block); the nblk_w blocks after them sum the split-K slabs of dW (4 columns per thread) and
+// (kurbm_kernels.h: bias_colsum_wave); the nblk_w blocks after them sum the split-K slabs of dW (4 columns per thread) and
 // either add lr * dW into W or store dW densely.
 __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a, int nbias, int nbias8) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < nbias8) {
-        __shared__ double sh[8 * BIAS_COLS];
-        if ((int)blockIdx.x < nbias) bias_colsum_block(a, blockIdx.x, tid, sh);
+        if ((int)blockIdx.x < nbias) bias_colsum_wave(a, blockIdx.x * 4 + (tid >> 6), tid & 63);
         return;
     }
     const int blk = (int)blockIdx.x - nbias8;

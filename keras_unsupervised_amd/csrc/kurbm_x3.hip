@@ -60,6 +60,22 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define KURBM_STAMP(var) do { } while (0)
 #endif
 
+// Fused reduction of the statistics GEMM: the rows [lo, hi) of its tile (tile-relative, multiples of 4) that k-slice z reduces
+// -- an even share of the tile's rows that lie inside the matrix, so the last row tile of 784 = 3 x 256 + 16 visible units
+// gives each of its slices 4 rows, not one of them 16.
+struct FuseRows { int lo, hi; };
+__device__ __forceinline__ FuseRows fuse_rows(const GemmArgsB& g, int m0, int z) {
+    int valid = g.M - m0;
+    const int bm_rows = (g.cfg == 2) ? 256 : 128;
+    if (valid > bm_rows) valid = bm_rows;
+    if (valid < 0) valid = 0;
+    const int per = ((valid + g.nsplit - 1) / g.nsplit + 3) & ~3;
+    FuseRows r;
+    r.lo = z * per < valid ? z * per : valid;
+    r.hi = r.lo + per < valid ? r.lo + per : valid;
+    return r;
+}
+
 // Wave-specialised: four LOADER waves beside the eight MFMA waves (768 threads, three waves per SIMD).  The loaders do all
 // the staging in a loop of their own -- LDS-DMA, `buffer_load_dwordx4 ... lds`: no register and no ds_write between memory
 // and LDS -- and the MFMA waves only read fragments, issue MFMAs and meet the loaders at the tile's barrier.  A stall of a
@@ -112,6 +128,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
     constexpr int NI_LDS = (EPI == EPI_HALFSTEP && NOISE == NOISE_BERNOULLI) ? 1 : 0;
     constexpr int DRAW_LDS_BYTES = NI_LDS * TM * NT * 16;
+    // EPI_SLAB, fused reduction: behind the fp32 patch of the tile sit a chunk of FUSE_RC x BN new weights (transposed mirror
+    // stores) and the word through which the polling lane tells the workgroup whether all slices of the tile arrived
+    constexpr int FUSE_RC = 4096 / BN;                                       // rows per chunk: 1024 float4 = 2 per MFMA thread
+    constexpr int FUSE_TILE_OFF = (BM * PROW32 + 255) / 256 * 256, FUSE_TILE_ROW = BN + 1;
+    constexpr int FUSE_FLAG_OFF = FUSE_TILE_OFF + FUSE_RC * FUSE_TILE_ROW * 4;
+    static_assert(EPI != EPI_SLAB || FUSE_FLAG_OFF + 16 <= SMEM_BYTES, "fused reduction: scratch behind the patch");
     static_assert(SMEM_BYTES + DRAW_LDS_BYTES <= 160 * 1024, "LDS per workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES + DRAW_LDS_BYTES];
 
@@ -159,6 +181,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #endif
 
     const int nwg = gridDim.x;
+    if (EPI == EPI_HALFSTEP && g.zero_words && blockIdx.x == 0)   // the arrival counters of the statistics launch behind this one
+        for (int i = tid; i < g.n_zero; i += NT + NTS) g.zero_words[i] = 0u;
     int bid = blockIdx.x;
     int z, bm, bn;
     if (g.xcd_r) {
@@ -571,7 +595,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         }
         __syncthreads();
         // keep the MFMA waves' epilogue barriers company: one per patch write, one between the pieces of a plane
-        if (EPI == EPI_SLAB || EPI == EPI_SOFTPLUS) __syncthreads();
+        if (EPI == EPI_SLAB && g.fuse) {
+            // fused reduction (below): the patch, the arrival, the poll's verdict, then two per chunk of the own rows
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+            if (*reinterpret_cast<volatile unsigned*>(smem + FUSE_FLAG_OFF)) {
+                const FuseRows fr = fuse_rows(g, m0, z);
+                for (int r0 = fr.lo; r0 < fr.hi; r0 += FUSE_RC) { __syncthreads(); __syncthreads(); }
+            }
+        } else if (EPI == EPI_SLAB || EPI == EPI_SOFTPLUS) __syncthreads();
         else if (g.out) {
             const int nb = (g.out_pieces == 3) ? 5 : 1;
             for (int q = 0; q < nb; ++q) __syncthreads();
@@ -591,6 +624,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     *reinterpret_cast<u32x4*>(smem + SMEM_BYTES + ((ni * TM + mi) * NT + tid) * 16) = u32x4{w[0], w[1], w[2], w[3]};
                 }
         }
+    }
+    if (EPI == EPI_SLAB && g.fuse) {
+        // fused reduction: the bias column sums -- their partials were complete before this launch -- under the flight of the
+        // first tiles, one wave per 8 columns (kurbm_kernels.h)
+        const int nbw = bias_waves(g.red);
+        for (int gi = (int)blockIdx.x * (NT / 64) + wave; gi < nbw; gi += nwg * (NT / 64)) bias_colsum_wave(g.red, gi, lane);
     }
     __builtin_amdgcn_s_setprio(2);   // the MFMA waves go first wherever a loader wave competes for issue (the reverse: no difference)
     if (nt > 0) {
@@ -636,14 +675,129 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                         (n0 + wn * WN + ni * 16 + l15 < g.N) ? acc[mi][ni][r] : 0.f;
         __syncthreads();
         constexpr int CH = BN / 4;   // 16-B chunks per row
+        if (!g.fuse) {
+#pragma unroll
+            for (int j = 0; j < BM * CH / NT; ++j) {
+                const int q = j * NT + tid, row = q / CH, c = q % CH;
+                const int gr = m0 + row, gc = n0 + 4 * c;
+                if (gr < g.M && gc < g.ld_slab) {   // ld_slab = N rounded up to 4: the chunk stays inside the row
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * PROW32 + 16 * c);
+                    *reinterpret_cast<f32x4*>(slab + (size_t)gr * g.ld_slab + gc) = v;
+                }
+            }
+            KURBM_STAMP_OUT();
+            return;
+        }
+        // ---- fused reduction: this launch is also the slab reduction, the weight update and the mirror rewrite -----------
+        // The nsplit k-slices of an output tile run at the same time (the host fuses only when the whole grid is resident,
+        // one workgroup per CU).  Slice z keeps the tile rows it will reduce itself -- its share [lo, hi) of the tile's rows
+        // inside the matrix -- in the LDS patch and stores only the OTHER rows to slab z, write-through (sc1: the readers sit
+        // on other XCDs, whose L2s do not snoop this one); every storing wave drains its stores, the workgroup meets, ONE
+        // lane counts it in on the tile's arrival counter (agent-scope atomic) and polls that word (sc1 loads) until all
+        // slices have arrived.  Then it sums its rows over the slabs IN SLAB ORDER -- its own from LDS, the others by sc1
+        // loads, which bypass this CU's L1 -- exactly the additions of k_reduce_apply_split, so W and the mirror come out
+        // bit-identical to the two-launch sequence; W += lr * sum, the new weights as bf16 pieces row-major and, through an
+        // LDS transpose, transposed.  (cdna_hip_programming.md, Guideline 16: R1 publish, sc1 consume; MI355X_MICROARCH.md,
+        // visibility table row 1.)  A poll that runs into its bound -- only possible when the grid is NOT resident -- sets
+        // bit 0 of the context's status word and leaves W alone: kurbm_ctx_status reports it, nothing hangs.
+        const FuseRows fr = fuse_rows(g, m0, z);
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        const rsrc_t dS = __builtin_amdgcn_make_buffer_rsrc(g.slab, 0, 0xFFFFFFFF, 0x00020000);
 #pragma unroll
         for (int j = 0; j < BM * CH / NT; ++j) {
             const int q = j * NT + tid, row = q / CH, c = q % CH;
             const int gr = m0 + row, gc = n0 + 4 * c;
-            if (gr < g.M && gc < g.ld_slab) {   // ld_slab = N rounded up to 4: the chunk stays inside the row
-                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * PROW32 + 16 * c);
-                *reinterpret_cast<f32x4*>(slab + (size_t)gr * g.ld_slab + gc) = v;
+            if (gr < g.M && gc < g.ld_slab && (row < fr.lo || row >= fr.hi)) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PROW32 + 16 * c);
+                __builtin_amdgcn_raw_buffer_store_b128(v, dS, (int)(((size_t)z * g.slab_stride + (size_t)gr * g.ld_slab + gc) * 4), 0, 16);
             }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its slab rows have left
+        __syncthreads();
+        if (tid == 0) {
+            unsigned ok = 1u;
+            if (g.nsplit > 1) {
+                gu32* cnt = (gu32*)(g.sync + bm * g.grid_n + bn);
+                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long t0, t1;
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.nsplit) {
+                    __builtin_amdgcn_s_sleep(4);
+                    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+                    if (t1 - t0 > 20000000ull) {   // 0.2 s of the 100 MHz clock: the grid is not resident
+                        ok = 0u;
+                        __hip_atomic_fetch_or((gu32*)g.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            *reinterpret_cast<volatile unsigned*>(smem + FUSE_FLAG_OFF) = ok;
+        }
+        __syncthreads();
+        if (*reinterpret_cast<volatile unsigned*>(smem + FUSE_FLAG_OFF) == 0u) { KURBM_STAMP_OUT(); return; }
+        const ReduceArgs& a = g.red;
+        float* ctile = reinterpret_cast<float*>(smem + FUSE_TILE_OFF);      // [FUSE_RC][BN + 1]
+        auto store3 = [&](uint16_t* dst, size_t plane, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
+            float v[4] = {v0, v1, v2, v3};
+            for (int j = 0; j < a.pieces; ++j) {
+                u32x2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<u32x2*>(dst + j * plane) = pk;
+                if (j + 1 < a.pieces) {
+                    v[0] -= bf16_bits_to_f32(pk.x & 0xFFFFu); v[1] -= bf16_bits_to_f32(pk.x >> 16);
+                    v[2] -= bf16_bits_to_f32(pk.y & 0xFFFFu); v[3] -= bf16_bits_to_f32(pk.y >> 16);
+                }
+            }
+        };
+        for (int r0 = fr.lo; r0 < fr.hi; r0 += FUSE_RC) {
+#pragma unroll
+            for (int j = 0; j < FUSE_RC * CH / NT; ++j) {
+                const int q = j * NT + tid, rl = q / CH, c = q % CH;
+                const int row = r0 + rl, gr = m0 + row, gc = n0 + 4 * c;
+                f32x4 w = {0.f, 0.f, 0.f, 0.f};
+                if (row < fr.hi && gr < g.M && gc < g.N) {
+                    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                    for (int z0 = 0; z0 < g.nsplit; z0 += 4) {   // four slabs in flight, added in slab order
+                        f32x4 v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int zz = z0 + e;
+                            if (zz >= g.nsplit) continue;
+                            if (zz == z) v[e] = *reinterpret_cast<const f32x4*>(smem + row * PROW32 + 16 * c);
+                            else v[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                     dS, (int)(((size_t)zz * g.slab_stride + (size_t)gr * g.ld_slab + gc) * 4), 0, 16));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (z0 + e < g.nsplit) sum += v[e];
+                    }
+                    float* wp = a.W + (size_t)gr * a.ldw + gc;                  // ldw % 4 == 0
+                    w = *reinterpret_cast<const f32x4*>(wp);
+                    w = w + sum * a.lr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (gc + e >= g.N) w[e] = 0.f;                          // the row padding stays zero
+                    *reinterpret_cast<f32x4*>(wp) = w;
+                    if (a.Wb) store3(a.Wb + (size_t)gr * a.ldWb + gc, a.planeWb, w.x, w.y, w.z, w.w);
+                }
+                float* ct = ctile + rl * FUSE_TILE_ROW + 4 * c;
+                ct[0] = w.x; ct[1] = w.y; ct[2] = w.z; ct[3] = w.w;
+            }
+            __syncthreads();
+            if (a.Wtb) {
+                // FUSE_RC / 4 lanes x 4 rows down a column of the chunk: runs of 2 FUSE_RC bytes per column and piece
+                constexpr int LPC = FUSE_RC / 4;
+#pragma unroll
+                for (int j = 0; j < LPC * BN / NT; ++j) {
+                    const int q = j * NT + tid, rr4 = (q % LPC) * 4, cl = q / LPC;
+                    const int cc = n0 + cl, rr = m0 + r0 + rr4;
+                    if (r0 + rr4 < fr.hi && cc < g.N && rr < a.ldWtb)
+                        store3(a.Wtb + (size_t)cc * a.ldWtb + rr, a.planeWtb, ctile[(rr4 + 0) * FUSE_TILE_ROW + cl],
+                               ctile[(rr4 + 1) * FUSE_TILE_ROW + cl], ctile[(rr4 + 2) * FUSE_TILE_ROW + cl],
+                               ctile[(rr4 + 3) * FUSE_TILE_ROW + cl]);
+                }
+            }
+            __syncthreads();
         }
         KURBM_STAMP_OUT();
         return;

@@ -9,7 +9,8 @@ weights.  Both lose part of an RBM: `get_config` omits `mode` (reference ku/ebm/
                          + input_dim + the RNG counters, so a reloaded RBM continues the same stream
     <stem>.safetensors   rbm_weight [n_vis, n_hid], rbm_hidden_bias [n_hid], rbm_visible_bias [n_vis], fp32;
                          with persistent=True also v_chain [batch_size, n_vis], the fantasy particles, so that a
-                         reloaded RBM continues the chain it was saved with
+                         reloaded RBM continues the chain it was saved with (data parallel: assembled over the ranks,
+                         each of which owns a band of its rows; save_rbm is then a collective call, rank 0 writes)
 
 and a DBN checkpoint is a JSON list of layer stems.
 """
@@ -32,13 +33,18 @@ def save_rbm(rbm, stem):
     meta = {"format": "kurbm-rbm", "version": FORMAT_VERSION, "config": cfg, "input_dim": int(W.shape[0]),
             "update_count": int(rbm._update_count), "call_count": int(rbm._call_count)}
     os.makedirs(os.path.dirname(os.path.abspath(stem)), exist_ok=True)
-    with open(stem + ".json", "w") as f:
-        json.dump(meta, f, indent=1, sort_keys=True)
     tensors = {"rbm_weight": np.ascontiguousarray(W, dtype=np.float32),
                "rbm_hidden_bias": np.ascontiguousarray(b_h, dtype=np.float32),
                "rbm_visible_bias": np.ascontiguousarray(b_v, dtype=np.float32)}
     if rbm._v_chain is not None:
-        tensors["v_chain"] = np.ascontiguousarray(rbm._v_chain.to_numpy(), dtype=np.float32)
+        # data parallel: every rank advances only its own rows of the chain, so the chain is assembled over the ranks first
+        # (RBM.full_chain: a collective -- every rank calls save_rbm; rank 0 writes the files)
+        tensors["v_chain"] = np.ascontiguousarray(rbm.full_chain(), dtype=np.float32)
+    from . import dp
+    if dp.world()[0] != 0:
+        return stem + ".json", stem + ".safetensors"
+    with open(stem + ".json", "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
     save_file(tensors, stem + ".safetensors")
     return stem + ".json", stem + ".safetensors"
 
@@ -63,8 +69,10 @@ def load_rbm(stem, device=None):
     rbm._call_count = int(meta.get("call_count", 0))
     if "v_chain" in t:
         from .engine import DeviceMatrix, device_guard
-        if t["v_chain"].shape[1] != meta["input_dim"]:
-            raise ValueError("checkpoint tensors do not match its config")
+        # (fit() reads and rewrites batch_size rows of the chain in place: any other row count is refused here, not there)
+        if t["v_chain"].shape != (int(cfg["hps"]["batch_size"]), meta["input_dim"]):
+            raise ValueError("checkpoint chain has shape %s, its config needs (%d, %d)"
+                             % (t["v_chain"].shape, int(cfg["hps"]["batch_size"]), meta["input_dim"]))
         with device_guard(rbm._dev.device):
             rbm._v_chain = DeviceMatrix.from_host(t["v_chain"], rbm._dev.device)
     return rbm

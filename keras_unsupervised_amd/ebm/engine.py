@@ -220,7 +220,12 @@ class DeviceRBM:
         return 1 if v.bf16_exact else 3
 
     def get_weights(self):
-        return self.W.to_numpy(), self.b_h.cpu().numpy(), self.b_v.cpu().numpy()
+        out = self.W.to_numpy(), self.b_h.cpu().numpy(), self.b_v.cpu().numpy()     # (device -> host copies: a sync)
+        bits = self.ctx.status()
+        if bits:
+            raise _lib.KurbmError("kurbm status %#x: a statistics launch that reduces its own slabs (KURBM_X3_FUSED=1) found its "
+                                  "grid not resident (CU mask / shared device) and skipped an update of W" % bits)
+        return out
 
     def set_weights(self, W=None, b_h=None, b_v=None):
         if W is not None:

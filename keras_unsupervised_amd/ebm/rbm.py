@@ -279,6 +279,12 @@ class RBM(object):
             self._v_chain = DeviceMatrix.zeros(bs, d.n_vis, d.device)
             first = min(bs, n)
             self._v_chain.t[:first].copy_(Vd.t[:first])
+        if self.persistent and (self._v_chain.rows != bs or self._v_chain.cols != d.n_vis):
+            # every step reads and rewrites `rows` rows of the chain in place: a chain kept from a fit with another batch
+            # size (or loaded from such a checkpoint) would be read past its end
+            raise ValueError("the persistent chain has shape (%d, %d); hps['batch_size'] = %d and %d visible units need (%d, %d) -- "
+                             "set rbm._v_chain = None to restart the chain from the data"
+                             % (self._v_chain.rows, self._v_chain.cols, bs, d.n_vis, bs, d.n_vis))
 
         # x3: the bf16 planes of every window of rows this fit walks are made once, here (the data is the same every
         # epoch); the fallback -- not enough HBM -- is the per-step conversion inside the library
@@ -347,6 +353,23 @@ class RBM(object):
         d.cd_step_dp(dp.get_comm(d.device), Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,
                      chain=CHAIN_W, row0=s_lo, v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo,
                      compute=self._compute(), planes=self._planes)
+
+    def full_chain(self):
+        """The persistent chain as ONE host array [batch_size, n_vis], or None.  Under data parallelism rank r advances
+        only its own rows of the chain (`_shard`); every other row it holds is stale.  This call is then COLLECTIVE: each
+        rank contributes its rows, zeros elsewhere, to a sum all-reduce on the library's communicator, and every rank
+        returns the assembled chain."""
+        if self._v_chain is None:
+            return None
+        rank, world = dp.world()
+        if world == 1:
+            return self._v_chain.to_numpy()
+        lo, hi = self._shard(self._v_chain.rows, rank, world)
+        with device_guard(self._dev.device):
+            own = torch.zeros_like(self._v_chain.t)
+            own[lo:hi].copy_(self._v_chain.t[lo:hi])
+            dp.get_comm(self._dev.device).allreduce_sum_(own.view(-1))
+            return own[: self._v_chain.rows, : self._v_chain.cols].contiguous().cpu().numpy()
 
     def _shard(self, rows, rank, world):
         """This rank's rows [lo, hi) of a batch of `rows` rows (persistent chains: fixed ownership of the chain's rows,

@@ -155,7 +155,9 @@ def _fit_worker(rank, world, port, case, q):
         r = RBM({"batch_size": c["bs"], "epochs": 2, "lr": LR}, NH, mode=c["mode"], seed=SEED, weights=W0,
                 cd_k=c["k"], persistent=c["persistent"], compute_dtype="fp32")
         assert r.fit(V, verbose=0) is None
-        q.put((rank, [w.copy() for w in r.get_weights()], list(r._dev.calls)))
+        # (collective: each rank owns a band of the chain's rows, RBM.full_chain assembles them -- what save_rbm stores)
+        chain = r.full_chain()
+        q.put((rank, [w.copy() for w in r.get_weights()], list(r._dev.calls), chain))
     finally:
         dist.destroy_process_group()
 
@@ -175,7 +177,7 @@ def _fit_reference(case):
             if chain is not None:
                 chain[:hi - lo] = ch["v_neg"]
             step += 1
-    return W, b_h, b_v
+    return W, b_h, b_v, chain
 
 
 def _run_fit(case, world=2):
@@ -195,9 +197,14 @@ def _run_fit(case, world=2):
 def _check_fit(case):
     res = _run_fit(case)
     ref = _fit_reference(case)
-    for a, b, r in zip(res[0][1], res[1][1], ref):
+    for a, b, r in zip(res[0][1], res[1][1], ref[:3]):
         assert np.array_equal(a, b)                                   # replicas stay bit-identical
         assert np.max(np.abs(a - r)) <= 1e-5                          # and track the single-process run
+    if ref[3] is None:
+        assert res[0][3] is None and res[1][3] is None
+    else:
+        # the assembled chain is the single-process chain on EVERY rank (a rank's own copy holds stale rows outside its band)
+        assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][3], ref[3])
     return res
 
 

@@ -109,3 +109,15 @@ def test_host_dbn_raises_what_the_reference_raises(ref, capsys):
     out = capsys.readouterr().out
     assert out.startswith(facts["fit_stdout"]) and out == "Train rbm_1.\nTrain rbm_2.\n"
     assert [s.fits for s in stubs] == [1, 1]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/ku/ebm/dbn.py"), reason="build container only: runs the reference's dbn.py")
+def test_ref_fixture_is_current(golden_dir, tmp_path, monkeypatch):
+    """Where the reference is present (the build container, never the GPU box): running it again reproduces the fixture."""
+    from oracle import make_ref_fixtures
+    monkeypatch.setattr(make_ref_fixtures, "GOLDEN_DIR", str(tmp_path))
+    make_ref_fixtures.main()
+    a, b = np.load(os.path.join(golden_dir, "ref_dbn.npz")), np.load(os.path.join(str(tmp_path), "ref_dbn.npz"))
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
