@@ -282,6 +282,15 @@ int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, 
                            int which, int stage, void* workspace, size_t workspace_bytes,
                            kurbm_stream_t stream);
 
+/* The per-step score of fit(verbose = 1), rbm.py:225-233, on the x3 path in ONE call with nothing returned to the host:
+ * fe = F(v_batch); v' = a one-step reconstruction of v_batch (fresh chain: opts->chain, sites 0 and 1, opts->step, opts->seed,
+ * opts->row0, opts->mode; opts->v_planes as for a step); fe' = F(v'); *score = mean |fe - fe'| (device float, 16-byte
+ * aligned); F (nullable, device [2 * rows]) receives fe then fe'.  Workspace as for kurbm_cd_step_x3 on the same rows; the
+ * caller reads *score back when it wants to print it (the reference prints every step: rbm.py:234). */
+int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch,
+                   int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, float* score, float* F, void* workspace,
+                   size_t workspace_bytes, kurbm_stream_t stream);
+
 /* kurbm_free_energy on the x3 path (rbm.py:73-76): workspace >= the bf16 pieces of v + one float per row and
  * 128-column tile (kurbm_x3_workspace_bytes of the same rows is enough). */
 int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v,
@@ -360,13 +369,21 @@ int kurbm_allreduce_sum_f32(kurbm_comm* comm, float* buf, size_t n, kurbm_stream
  * opts->apply = 1 -- W, b_h, b_v += lr * (summed delta) and the weight-piece mirror rewritten, in one launch, once the
  * last all-reduce has landed.  opts->delta_out (packed, required) holds the SUMMED statistics afterwards.  rows = 0
  * is legal (a rank that owns no rows of a remainder batch contributes zeros; v_batch is not read).  n_chunks <= 0:
- * the library picks (one range, all-reduced on `stream` itself: on MI355X / ROCm 7 the hand-off between two streams
- * costs more than a 3.2 MB all-reduce can hide -- DESIGN.md section 5).  Every rank must pass the same n_chunks.  All
- * work is ordered on `stream` from the caller's point of view.
+ * the library picks by the size of the exchange -- ONE range, all-reduced on `stream` itself, up to 8 MB (on MI355X /
+ * ROCm 7 the hand-off between two streams costs more than a 3.2 MB all-reduce can hide), ranges of ~16 MB above (the
+ * 67 MB of a 4096 x 4096 RBM travel as four) -- DESIGN.md section 5.  With several ranges each one is APPLIED (its rows of
+ * W, its part of the mirror) on the comm stream as soon as its all-reduce has landed, under the statistics GEMM of the
+ * next.  Every rank must pass the same n_chunks.  All work is ordered on `stream` from the caller's point of view.
+ * Every argument is checked before the first collective is enqueued, so a refused call has not joined an all-reduce
+ * (the checks depend on arguments all ranks share; `rows` may differ).
  */
 int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                         const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks,
                         void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+/* The same step on the rounded-bf16 path (BASELINE.json config 5: 4096 x 4096, 67 MB of packed sums per step). */
+int kurbm_cd_step_bf16_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                          const float* v_batch, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks, void* workspace,
+                          size_t workspace_bytes, kurbm_stream_t stream);
 
 /* *flag (device int, zeroed by the caller) |= 1 if some element of x [rows][ld] is not exactly representable in bf16,
  * |= 2 if some element is neither 0.0 nor 1.0.  0: v_pieces = 1 | KURBM_V_BINARY; 2: v_pieces = 1; else 3. */

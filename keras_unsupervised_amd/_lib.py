@@ -71,6 +71,7 @@ SIGNATURES = {
     "kurbm_cd_step_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _vp, _sz, _vp]),
     "kurbm_cd_step_x3_stage": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _i, _vp, _sz, _vp]),
     "kurbm_free_energy_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "kurbm_score_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _vp, _vp, _vp, _sz, _vp]),
     "kurbm_cd_epoch_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _i, _OP, _vp, _sz, _vp]),
     "kurbm_cd_chain_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _vp, _sz, _vp]),
     "kurbm_x3_stats_rows": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _i, _vp, _sz, _vp]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "kurbm_comm_destroy": (None, [_vp]),
     "kurbm_allreduce_sum_f32": (_i, [_vp, _vp, _sz, _vp]),
     "kurbm_cd_step_x3_dp": (_i, [_vp, _vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _vp, _sz, _vp]),
+    "kurbm_cd_step_bf16_dp": (_i, [_vp, _vp, _PP, _vp, _sz, _vp, _i, _i, _OP, _i, _vp, _sz, _vp]),
 }
 
 ABI_VERSION = 4

@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_COUNT };
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
@@ -37,6 +37,7 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_REDUCE_TR", 0},        // tile height (16 / 32 / 64) of the slab-reduce + mirror launch; 0: by the grid it makes
     {"KURBM_X3_FUSED", 0},         // 1: the statistics GEMM reduces its own split-K slabs where its grid is resident (bit-identical to the
                                    //    separate reduce launch and no faster: 117.7 against 117.5 us per step)
+    {"KURBM_DP_CHUNKS", 0},        // row ranges of dW in the data-parallel step when the caller passes n_chunks <= 0; 0: by message size
 };
 
 struct kurbm_ctx {
@@ -759,8 +760,11 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         // 2: 256 x 64 tiles (fewer bytes per k-tile).  Whole 256-row tiles only: the bias partial rows are laid out
         // per 64 rows, two per 128-row tile, and an even number of those is what both tilings agree on
         const int tall = ctx->knob[KN_X3_TALL];
+        // (x3 only: with ONE piece per weight the B tile is the light operand and 128 x 128 tiles take fewer bytes per MFMA --
+        //  A 16 KB + B 16 KB against 32 + 8 for the same 128 MFMAs per wave pair; 4096 x 4096 PCD-10, 1024 rows: 0.977 against
+        //  1.033 ms per step)
         if (!g.cfg && ceil_div(rows, 128) % 2 == 0 &&
-            (tall == 1 || (tall < 0 && (rows / 256) * ceil_div(g.N, 64) * 4 >= 3 * ctx->ncu))) g.cfg = 2;
+            (tall == 1 || (tall < 0 && m.pieces == 3 && (rows / 256) * ceil_div(g.N, 64) * 4 >= 3 * ctx->ncu))) g.cfg = 2;
         // (64-column tiles: a row-major plane is the next GEMM's A operand, k-padded to 128 -- cover the padded row)
         g.grid_m = ceil_div(rows, g.cfg == 2 ? 256 : 128);
         g.grid_n = g.cfg ? ceil_div(o.out ? round_up(g.N, 128) : g.N, 64) : ceil_div(g.N, 128);
@@ -1156,6 +1160,81 @@ int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
     return KURBM_OK;
 }
 
+int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch, int v_pieces,
+                   int rows, int ldv, const kurbm_cd_opts* o, float* score, float* F, void* workspace, size_t workspace_bytes,
+                   kurbm_stream_t stream) {
+    // rbm.py:225-233 in one call, nothing returned to the host: F(v) [GEMM + softplus row sums on the planes of v], h ~ p(h | v)
+    // [half step], v' ~ p(v | h) [half step; its row-major plane feeds the next GEMM, an fp32 copy the v'.b_v term], F(v'),
+    // then |F - F'| per row and its mean into *score.  Draws: chain o->chain, sites 0 (h) and 1 (v'), step o->step -- the
+    // counters RBM._score has always used.
+    if (!score || !aligned16(score)) return fail(KURBM_ERR_ARG, "score is null or misaligned");
+    if (int e = check_cd_args(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, workspace, workspace_bytes, false)) return e;
+    const bool v_binary = (v_pieces == (1 | KURBM_V_BINARY));
+    if (v_binary) v_pieces = 1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, 3);
+    WorkspaceB w = carve_bf16(ctx, workspace, rows, p->n_vis, p->n_hid, 3, v_pieces);
+    const bool gauss = (o->mode == KURBM_MODE_VISIBLE_GAUSSIAN);
+    const bool byt = ctx->knob[KN_X3_BYTES] != 0;
+    const bool vbytes = byt && v_binary, hbytes = byt, nbytes = byt && !gauss;
+    const bool f8pos = v_binary && ctx->knob[KN_X3_F8POS] != 0;      // (only so that a conversion here writes what a step would)
+    const int vn_pieces = gauss ? 3 : 1;
+    const uint32_t base = o->chain * 64u;
+    // row partials of the two free-energy GEMMs live in the (unused here) slab area; |F - F'| per row behind them
+    const int ncol = ceil_div(p->n_hid, 128), ld_rp = round_up(rows, 4);
+    if ((size_t)(2 * ncol + 1) * ld_rp > w.slab_stride) return fail(KURBM_ERR_WORKSPACE, "workspace too small for the score's row partials");
+    float* rp0 = w.slab; float* rp1 = w.slab + (size_t)ncol * ld_rp; float* absdiff = w.slab + (size_t)2 * ncol * ld_rp;
+    if (o->v_planes) {
+        const VPlanes vp = carve_vplanes(ctx, o->v_planes, rows, p->n_vis, v_pieces);
+        w.vb = vp.vb;
+    } else {
+        HIP_TRY(launch_f32_to_bf16(v_batch, rows, p->n_vis, ldv, w.vb, w.Lv, w.Kb, nullptr, 0, 0, v_pieces, w.planeV, 0, nullptr, 0, st,
+                                   0, vbytes ? 1 : 0));
+    }
+    (void)f8pos;
+    auto softplus_gemm = [&](const uint16_t* A, int a_pieces, bool a_bytes, float* rowpart) -> int {
+        GemmArgsB g;
+        memset(&g, 0, sizeof g);
+        g.A0 = A; g.lda = w.Lv; g.a_plane0 = w.planeV; g.a_bytes = a_bytes ? 1 : 0;
+        g.B0 = m.Wtb; g.ldb = m.ldWt; g.b_plane0 = m.planeWt;
+        g.M = rows; g.N = p->n_hid; g.K = round_up(p->n_vis, 64);
+        g.grid_m = ceil_div(rows, 128); g.grid_n = ncol;
+        g.nseg = pb_codes(ctx, a_pieces, 3, 0u, &g.seg_codes, 0);
+        g.pb_max = 3;
+        g.nkt = g.K / 64; g.inv_nkt = inv_of(g.nkt);
+        g.kt_total = g.nseg * g.nkt; g.kt_per_split = g.kt_total; g.nsplit = 1;
+        g.m_fastest = 1;
+        g.bias = p->b_h;
+        g.rowpart = rowpart; g.ld_rowpart = ld_rp;
+        g.xcd2d = ctx->knob[KN_X3_XCD2D];
+        HIP_TRY(launch_gemm_pb(EPI_SOFTPLUS, g, st));
+        return KURBM_OK;
+    };
+    int e;
+    if ((e = softplus_gemm(w.vb, v_pieces, vbytes, rp0))) return e;                                   // F(v)      rbm.py:227
+    RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
+    {
+        HalfOutB ho;
+        ho.out = w.hb; ho.ldo = w.Lh; ho.out_bytes = hbytes;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Lv, v_pieces, w.planeV, rows, gauss ? ACT_RELU : ACT_SIGMOID, NOISE_BERNOULLI,
+                             &r, ho, st, vbytes))) return e;                                            // h          rbm.py:230
+    }
+    r = make_rng(o->seed, o->row0, base + 1u, o->step);
+    {
+        HalfOutB ho;
+        ho.out = w.v2b; ho.ldo = w.Lv; ho.out_pieces = vn_pieces; ho.out_plane = w.planeV; ho.out_bytes = nbytes;
+        ho.out_f32 = w.tmp32; ho.ldo32 = w.ldv32;
+        if ((e = half_step_b(ctx, LAYOUT_HV, p, m, w.hb, w.Lh, 1, 0, rows, gauss ? ACT_LINEAR : ACT_SIGMOID,
+                             gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, &r, ho, st, hbytes))) return e;   // v'
+    }
+    if ((e = softplus_gemm(w.v2b, vn_pieces, nbytes, rp1))) return e;                                 // F(v')     rbm.py:231
+    ScoreArgs a;
+    a.v = v_batch; a.v1 = w.tmp32; a.b_v = p->b_v; a.rowpart = rp0; a.rowpart1 = rp1; a.F = F; a.absdiff = absdiff; a.score = score;
+    a.rows = rows; a.n_vis = p->n_vis; a.ldv = ldv; a.ldv1 = w.ldv32; a.ncol_tiles = ncol; a.ld_rowpart = ld_rp;
+    HIP_TRY(launch_score(a, st));                                                                      // mean |F - F'|  rbm.py:233
+    return KURBM_OK;
+}
+
 int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* V,
                       int v_pieces, int n_rows, int ldv, int batch_size, const kurbm_cd_opts* opts, void* workspace,
                       size_t workspace_bytes, kurbm_stream_t stream) {
@@ -1195,9 +1274,46 @@ int kurbm_x3_stats_rows(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, siz
                        m_lo, m_hi);
 }
 
-int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p, void* mirror, size_t mirror_bytes,
-                        const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks,
-                        void* workspace, size_t workspace_bytes, kurbm_stream_t stream) {
+// W (rows [m_lo, m_hi)), and with `bias` b_h and b_v, += lr * (packed delta); the bf16 pieces of the new weights rewritten
+// in both orientations -- one launch: the packed delta is one "slab" and one row of bias partials each.
+static int apply_delta_rows(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, int pieces, const float* delta,
+                            float lr, int which, int m_lo, int m_hi, bool bias, hipStream_t st) {
+    const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, pieces);
+    if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
+    ReduceArgs a;
+    memset(&a, 0, sizeof a);
+    const size_t nw = (size_t)p->n_vis * p->n_hid;
+    a.slab = delta + (size_t)m_lo * p->n_hid; a.slab_stride = 0; a.nslab = 1; a.ld_slab = p->n_hid;
+    a.n_vis = m_hi - m_lo; a.n_vis_bias = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw; a.lr = lr;
+    a.W = p->W + (size_t)m_lo * p->ldw;
+    if (bias) {
+        a.part_h = delta + nw; a.nrow_tiles_h = 1; a.ld_part_h = p->n_hid; a.b_h = (which & 2) ? p->b_h : nullptr;
+        a.part_v = delta + nw + p->n_hid; a.nrow_tiles_v = 1; a.ld_part_v = p->n_vis; a.b_v = (which & 4) ? p->b_v : nullptr;
+    }
+    a.Wb = m.Wb + (size_t)m_lo * m.ldW; a.ldWb = m.ldW; a.planeWb = m.planeW;
+    a.Wtb = m.Wtb + m_lo; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = pieces;
+    // the transposed mirror's k columns of these rows; the last range also rewrites the zero k padding behind n_vis
+    a.wtb_k_ext = (m_hi == p->n_vis) ? m.ldWt - m_lo : m_hi - m_lo;
+    a.tile_rows = ctx->knob[KN_REDUCE_TR];
+    HIP_TRY(launch_reduce_apply_split(a, st));
+    return KURBM_OK;
+}
+
+// Row ranges of dW for an exchange of `bytes` bytes.  ONE range up to 12 MiB: on MI355X / ROCm 7 a hand-off between two HIP
+// streams costs 12-16 us per event wait and a statistics GEMM cut in two ~13 us (tools/dp_times.py) -- ~49 us before the second
+// range's all-reduce can start, more than the half of a 3.2 MB exchange it could hide (ring wire time 37 us at 8 ranks).  Above
+// that, ranges of ~16 MiB (ring wire time ~190 us each, the hand-offs ~50 us in all): the 67 MB of a 4096 x 4096 RBM travel
+// as four, and all but the last range's exchange and apply run under the statistics GEMM of the next.
+static int auto_chunks(size_t bytes) {
+    if (bytes <= (12u << 20)) return 1;
+    int n = (int)((bytes + (8u << 20)) / (16u << 20));
+    if (n < 2) n = 2;
+    return n > kurbm_comm::MAX_CHUNKS ? kurbm_comm::MAX_CHUNKS : n;
+}
+
+static int cd_step_dp_any(kurbm_ctx* ctx, kurbm_comm* comm, int pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                          const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks,
+                          void* workspace, size_t workspace_bytes, kurbm_stream_t stream) {
     if (!ctx || !comm || !opts) return fail(KURBM_ERR_ARG, "null argument");
     if (int e = check_params(p)) return e;
     if (!opts->delta_out || !aligned16(opts->delta_out)) return fail(KURBM_ERR_ARG, "delta_out (the packed sums) is required, 16-byte aligned");
@@ -1205,15 +1321,11 @@ int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p,
     if (rows < 0) return fail(KURBM_ERR_ARG, "rows must be >= 0");
     // everything cd_step_any would refuse is refused HERE, before the first collective is enqueued: a rank that returned
     // an error from inside the sequence would leave the other ranks waiting in ncclAllReduce
-    if (int e = check_cd_args(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, opts, workspace, workspace_bytes, true)) return e;
+    if (int e = check_cd_args(ctx, pieces, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, opts, workspace, workspace_bytes, true)) return e;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t nw = (size_t)p->n_vis * p->n_hid, ntot = nw + p->n_hid + p->n_vis;
     // row ranges of dW: boundaries on multiples of 128 (the statistics tile), the same on every rank
-    // automatic = ONE range, the all-reduce on the caller's stream.  Measured on MI355X (tools/dp_times.py, 784 x 1024, B = 4096,
-    // 1-rank communicator): one range 139 us per step (= the local step), two 188 us, three 208 us -- a hand-off between two
-    // HIP streams costs ~16 us per event wait and the split statistics GEMM ~13 us, more than the part of a 3.2 MB all-reduce
-    // that the second range could hide.
-    if (n_chunks <= 0) n_chunks = 1;
+    if (n_chunks <= 0) n_chunks = ctx->knob[KN_DP_CHUNKS] > 0 ? ctx->knob[KN_DP_CHUNKS] : auto_chunks(ntot * sizeof(float));
     if (n_chunks > kurbm_comm::MAX_CHUNKS) n_chunks = kurbm_comm::MAX_CHUNKS;
     int bound[kurbm_comm::MAX_CHUNKS + 1];
     int nc = 0;
@@ -1225,15 +1337,18 @@ int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p,
     bound[++nc] = p->n_vis;
     kurbm_cd_opts o = *opts;
     o.apply = 0;
+    // several ranges: each one is applied (W rows, the mirror's pieces of those rows) on the comm stream as soon as its
+    // all-reduce has landed, under the statistics GEMM of the next; that needs 16-byte-aligned rows in the packed buffer
+    const bool apply_ranges = opts->apply && nc > 1 && (p->n_hid & 3) == 0;
     if (rows == 0) HIP_TRY(hipMemsetAsync(o.delta_out, 0, ntot * sizeof(float), st));
     else if (nc > 1)
-        if (int e = cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream, 8))
+        if (int e = cd_step_any(ctx, pieces, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream, 8))
             return e;
     for (int c = 0; c < nc; ++c) {
         if (rows > 0) {
             const int e = (nc == 1)
-                ? cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream)
-                : cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream, 7,
+                ? cd_step_any(ctx, pieces, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream)
+                : cd_step_any(ctx, pieces, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream, 7,
                               bound[c], bound[c + 1]);
             if (e) return e;
         }
@@ -1246,14 +1361,33 @@ int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p,
         HIP_TRY(hipEventRecord(comm->ev_ready[c], st));
         HIP_TRY(hipStreamWaitEvent(comm->stream, comm->ev_ready[c], 0));
         if (int e = comm_allreduce_sum(comm, o.delta_out + lo, hi - lo, comm->stream)) return e;
+        if (apply_ranges)
+            if (int e = apply_delta_rows(ctx, p, mirror, mirror_bytes, pieces, o.delta_out, o.lr, 7, bound[c], bound[c + 1], c + 1 == nc, comm->stream))
+                return e;
     }
     if (nc > 1) {
         HIP_TRY(hipEventRecord(comm->ev_done, comm->stream));
         HIP_TRY(hipStreamWaitEvent(st, comm->ev_done, 0));
     }
-    if (opts->apply)
-        return kurbm_x3_apply_delta(ctx, p, mirror, mirror_bytes, o.delta_out, o.lr, 7, stream);
+    if (opts->apply && !apply_ranges) {
+        if (pieces == 3) return kurbm_x3_apply_delta(ctx, p, mirror, mirror_bytes, o.delta_out, o.lr, 7, stream);
+        if ((p->n_hid & 3) == 0) return apply_delta_rows(ctx, p, mirror, mirror_bytes, pieces, o.delta_out, o.lr, 7, 0, p->n_vis, true, st);
+        if (int e = kurbm_apply_delta(ctx, p, o.delta_out, o.lr, 7, stream)) return e;
+        return mirror_refresh_any(ctx, pieces, p, mirror, mirror_bytes, stream);
+    }
     return KURBM_OK;
+}
+
+int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                        const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks,
+                        void* workspace, size_t workspace_bytes, kurbm_stream_t stream) {
+    return cd_step_dp_any(ctx, comm, 3, p, mirror, mirror_bytes, v_batch, v_pieces, rows, ldv, opts, n_chunks, workspace, workspace_bytes, stream);
+}
+
+int kurbm_cd_step_bf16_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                          const float* v_batch, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks, void* workspace,
+                          size_t workspace_bytes, kurbm_stream_t stream) {
+    return cd_step_dp_any(ctx, comm, 1, p, mirror, mirror_bytes, v_batch, 1, rows, ldv, opts, n_chunks, workspace, workspace_bytes, stream);
 }
 
 int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* delta,
@@ -1261,30 +1395,17 @@ int kurbm_x3_apply_delta(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
     if (!ctx || !delta) return fail(KURBM_ERR_ARG, "null argument");
     if (int e = check_params(p)) return e;
     if (!mirror || !aligned16(mirror) || !aligned16(delta)) return fail(KURBM_ERR_ARG, "mirror / delta null or misaligned");
-    const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, 3);
-    if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if ((p->n_hid & 3) || !(which & 1)) {   // packed rows not 16-byte aligned, or W untouched: two launches
+        const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, 3);
+        if (m.bytes > mirror_bytes) return fail(KURBM_ERR_WORKSPACE, "mirror too small: need %zu bytes, got %zu", m.bytes, mirror_bytes);
         if (int e = kurbm_apply_delta(ctx, p, delta, lr, which, stream)) return e;
         if (which & 1)
             HIP_TRY(launch_f32_to_bf16(p->W, p->n_vis, p->n_hid, p->ldw, m.Wb, m.ldW, p->n_vis, m.Wtb, m.ldWt, p->n_hid, 3,
                                        m.planeW, m.planeWt, nullptr, 0, st));
         return KURBM_OK;
     }
-    // the packed delta is one "slab" and one row of bias partials each: W += lr * dW, pieces rewritten, one launch
-    ReduceArgs a;
-    memset(&a, 0, sizeof a);
-    const size_t nw = (size_t)p->n_vis * p->n_hid;
-    a.slab = delta; a.slab_stride = 0; a.nslab = 1; a.ld_slab = p->n_hid;
-    a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw; a.lr = lr;
-    a.W = p->W;
-    a.part_h = delta + nw; a.nrow_tiles_h = 1; a.ld_part_h = p->n_hid; a.b_h = (which & 2) ? p->b_h : nullptr;
-    a.part_v = delta + nw + p->n_hid; a.nrow_tiles_v = 1; a.ld_part_v = p->n_vis; a.b_v = (which & 4) ? p->b_v : nullptr;
-    a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
-    a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = 3;
-    a.tile_rows = ctx->knob[KN_REDUCE_TR];
-    HIP_TRY(launch_reduce_apply_split(a, st));
-    return KURBM_OK;
+    return apply_delta_rows(ctx, p, mirror, mirror_bytes, 3, delta, lr, which, 0, p->n_vis, true, st);
 }
 
 size_t kurbm_x3_planes_bytes(kurbm_ctx* ctx, int rows, int n_vis, int v_pieces) {

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int ti
 #pragma unroll
             for (int j = 0; j < CVT / CPP; ++j) {
                 const int cl = cq + CPP * j, cc = bx * CVT + cl;
-                if (cc < a.n_hid && rr < a.ldWtb)
+                if (cc < a.n_hid && rr < (a.wtb_k_ext ? a.wtb_k_ext : a.ldWtb))
                     store3(a.Wtb + (size_t)cc * a.ldWtb + rr, a.planeWtb, tile[rr4 + 0][cl], tile[rr4 + 1][cl], tile[rr4 + 2][cl],
                            tile[rr4 + 3][cl]);
             }
@@ -254,7 +254,7 @@ hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st) {
     // the tile grid covers the padded extents of both mirrors (their zero k padding is written here)
     int r_ext = a.n_vis, c_ext = a.n_hid;
     if (a.Wb && a.ldWb > c_ext) c_ext = a.ldWb;
-    if (a.Wtb && a.ldWtb > r_ext) r_ext = a.ldWtb;
+    if (a.Wtb && (a.wtb_k_ext ? a.wtb_k_ext : a.ldWtb) > r_ext) r_ext = a.wtb_k_ext ? a.wtb_k_ext : a.ldWtb;
     const int nb = bias_blocks(a);
     const int tiles_x = (c_ext + CVT - 1) / CVT;
     // taller tiles = longer runs in the transposed mirror (2 TR bytes per column) but fewer workgroups

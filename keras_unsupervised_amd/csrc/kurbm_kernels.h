@@ -90,6 +90,8 @@ struct ReduceArgs {
     uint16_t* Wb;         // [pieces][n_vis][ldWb]   nullable
     uint16_t* Wtb;        // [pieces][n_hid][ldWtb]
     int ldWb, ldWtb, pieces;
+    int wtb_k_ext;        // k_reduce_apply_split: k columns of Wtb (from its pointer) this launch may write; 0 = ldWtb.  A launch on a
+                          // row RANGE of W writes its own rows' columns only (the last range also the zero k padding behind them)
     int tile_rows;        // k_reduce_apply_split: forced tile height 16 / 32 / 64 (ctx knob KURBM_REDUCE_TR); 0 = by the grid it makes
     size_t planeWb, planeWtb;
 };
@@ -151,6 +153,21 @@ struct ApplyArgs {
     int n_vis, n_hid, ldw;
     float lr;
 };
+
+// The score of fit(verbose = 1), rbm.py:225-233: F(v) and F(v') per row from the softplus row partials of two GEMMs, then
+// mean |F(v) - F(v')| into ONE device float (k_score_rows, k_score_mean: kurbm_kernels.hip)
+struct ScoreArgs {
+    const float* v;        // [rows][ldv]  the batch
+    const float* v1;       // [rows][ldv1] its one-step reconstruction v' (fp32 plane)
+    const float* b_v;
+    const float* rowpart;  // [ncol_tiles][ld_rowpart] of v
+    const float* rowpart1; // ... of v'
+    float* F;              // nullable [2 * rows]: F(v) then F(v')
+    float* absdiff;        // [rows]
+    float* score;          // [1]
+    int rows, n_vis, ldv, ldv1, ncol_tiles, ld_rowpart;
+};
+hipError_t launch_score(const ScoreArgs& a, hipStream_t st);
 
 struct FinishArgs {
     const float* v;

@@ -726,6 +726,52 @@ __global__ __launch_bounds__(256) void k_free_energy_finish(FinishArgs a) {
     }
 }
 
+// The score of fit(verbose = 1) (rbm.py:225-233).  One wave per row: F(v) = -(v.b_v + its softplus partials), the same for
+// the reconstruction v', |F(v) - F(v')| to absdiff[row]; then ONE block adds the rows up in a fixed order (double) and
+// writes the mean: nothing returns to the host, the caller copies the float back when it wants to print it.
+__global__ __launch_bounds__(256) void k_score_rows(ScoreArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= a.rows) return;
+    float t = 0.f, t1 = 0.f;
+    for (int c = lane; c < a.n_vis; c += 64) {
+        const float b = a.b_v[c];
+        t += a.v[(size_t)row * a.ldv + c] * b;
+        t1 += a.v1[(size_t)row * a.ldv1 + c] * b;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); t1 += __shfl_xor(t1, o); }
+    if (lane == 0) {
+        float sp = 0.f, sp1 = 0.f;
+        for (int i = 0; i < a.ncol_tiles; ++i) {
+            sp += a.rowpart[(size_t)i * a.ld_rowpart + row];
+            sp1 += a.rowpart1[(size_t)i * a.ld_rowpart + row];
+        }
+        const float F = -(t + sp), F1 = -(t1 + sp1);
+        if (a.F) { a.F[row] = F; a.F[a.rows + row] = F1; }
+        a.absdiff[row] = fabsf(F - F1);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_score_mean(ScoreArgs a) {
+    __shared__ double part[1024];
+    double s = 0.;
+    for (int r = threadIdx.x; r < a.rows; r += 1024) s += (double)a.absdiff[r];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.score[0] = (float)(part[0] / (double)a.rows);
+}
+
+hipError_t launch_score(const ScoreArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_score_rows, dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_score_mean, dim3(1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     static_assert(KS == 2, "fragment buffers alternate with the k-step");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;
-    static_assert(!AB || EPI == EPI_HALFSTEP, "byte A tiles: half steps");
+    static_assert(!AB || EPI == EPI_HALFSTEP || EPI == EPI_SOFTPLUS, "byte A tiles: half steps and the free-energy GEMM");
     constexpr int A_BYTES = BM * ROWB, B1_BYTES = BN * ROWB, B_BYTES = PB * B1_BYTES;   // (AB: A_BYTES is a BLOCK, 128 k deep)
     // LDS: two stages [A tile | B pieces]; AB: two A blocks, then two stages of B pieces
     constexpr int STAGE = AB ? B_BYTES : A_BYTES + B_BYTES;
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (cok) rsum[mi][r] += softplusf(acc[mi][ni][r] + bias);
+                    if (cok) rsum[mi][r] += softplusf((AB ? 0.5f * acc[mi][ni][r] : acc[mi][ni][r]) + bias);   // (AB: the A bytes read as 2.0)
         }
         float* red = reinterpret_cast<float*>(smem);   // [WAVES_N][BM]
 #pragma unroll
@@ -1085,8 +1085,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 // the combinations the host plans are instantiated
 template <int PBN, int E, int NZ>
 static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
-    if (g.a_bytes) {   // byte A planes: the half steps of the x3 path
-        if constexpr (E == EPI_HALFSTEP && PBN == 3) {
+    if (g.a_bytes) {   // byte A planes: the half steps of the x3 path, and the free-energy GEMM of a 0/1 plane
+        if constexpr (E == EPI_SOFTPLUS && PBN == 3) {
+            if (g.cfg != 0) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+            return hipGetLastError();
+        } else if constexpr (E == EPI_HALFSTEP && PBN == 3) {
             if (g.cfg == 2) hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             else if (g.cfg == 0) hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             else return hipErrorInvalidValue;

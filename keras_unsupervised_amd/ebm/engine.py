@@ -5,7 +5,6 @@ PyTorch is used for exactly three things here: owning device memory (``torch.zer
 of the contrastive-divergence path happens inside ``libkurbm.so``.
 """
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -336,25 +335,32 @@ class DeviceRBM:
                    v_chain=None, v_chain_row=0, compute="x3", n_chunks=0, planes=None):
         """One data-parallel CD-k update: this rank's chain on rows [row_start, +rows) of v (`row0` = their index in
         the global batch), the packed sums all-reduced over `comm` (dp.Comm), the summed update applied.  rows may be 0
-        (a rank without rows of a remainder batch still joins the all-reduce).  On the x3 path all of it is ONE library
-        call (kurbm_cd_step_x3_dp) that overlaps the all-reduce of the first rows of dW with the statistics GEMM of the
-        rest; the other paths run emit -> kurbm_allreduce_sum_f32 -> apply."""
+        (a rank without rows of a remainder batch still joins the all-reduce).  On the x3 and rounded-bf16 paths all of it
+        is ONE library call (kurbm_cd_step_x3_dp / _bf16_dp) that, above 8 MB of sums, cuts dW into row ranges and
+        all-reduces + applies range i on its comm stream under the statistics GEMM of range i + 1; the fp32-MFMA path runs
+        emit -> kurbm_allreduce_sum_f32 -> apply."""
         delta = self.delta_buffer()
-        n_chunks = n_chunks or int(os.environ.get("KURBM_DP_CHUNKS", "0"))      # 0: the library's choice (one range)
-        if compute == "x3":
+        # n_chunks 0: the library's choice (by the size of the exchange; ctx knob KURBM_DP_CHUNKS overrides)
+        if compute in ("x3", "bf16"):
+            pieces = 3 if compute == "x3" else 1
             with torch.cuda.device(self.device):
-                vp = self._x3_pieces(v, v_chain, mode)
-                mir, ws = self.mirror(3), self.workspace_bf16(max(rows, 1), k, 3, vp)
+                vp = self._x3_pieces(v, v_chain, mode) if pieces == 3 else 1
+                mir, ws = self.mirror(pieces), self.workspace_bf16(max(rows, 1), k, pieces, vp)
                 opts = CdOpts(int(k), int(mode), float(lr), 1, delta.data_ptr(),
                               v_chain.ptr(v_chain_row) if v_chain is not None else None,
                               int(seed), int(row0), int(step) & 0xFFFFFFFF, int(chain))
-                if planes is not None and rows > 0:
+                if planes is not None and rows > 0 and pieces == 3:
                     opts.v_planes = planes.ptr(v, row_start, rows, vp)
-                check(self.lib.kurbm_cd_step_x3_dp(self.ctx.handle, comm.handle, C.byref(self.params), mir.data_ptr(),
-                                                   mir.numel(), v.ptr(row_start), vp, int(rows), v.ld, C.byref(opts),
-                                                   int(n_chunks), ws.data_ptr(), ws.numel(), self._stream()))
-            self._weights_written(kept=3)
-            self._mirrors[3][1] = False
+                if pieces == 3:
+                    check(self.lib.kurbm_cd_step_x3_dp(self.ctx.handle, comm.handle, C.byref(self.params), mir.data_ptr(),
+                                                       mir.numel(), v.ptr(row_start), vp, int(rows), v.ld, C.byref(opts),
+                                                       int(n_chunks), ws.data_ptr(), ws.numel(), self._stream()))
+                else:
+                    check(self.lib.kurbm_cd_step_bf16_dp(self.ctx.handle, comm.handle, C.byref(self.params), mir.data_ptr(),
+                                                         mir.numel(), v.ptr(row_start), int(rows), v.ld, C.byref(opts),
+                                                         int(n_chunks), ws.data_ptr(), ws.numel(), self._stream()))
+            self._weights_written(kept=pieces)
+            self._mirrors[pieces][1] = False
             if rows > 0:
                 self._chain_written(v_chain, mode)
             return
@@ -469,6 +475,21 @@ class DeviceRBM:
             check(self.lib.kurbm_free_energy(self.ctx.handle, C.byref(self.params), v.ptr(row_start), rows, v.ld,
                                              F.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return F
+
+    def score_x3(self, v, rows, row_start, seed, step, mode, chain, planes=None):
+        """mean |F(v) - F(v')| of rows [row_start, +rows) of v, v' a fresh one-step reconstruction (rbm.py:225-233), in ONE
+        library call on the x3 kernels; returns a device tensor whose element 0 is the score -- nothing is read back here."""
+        with torch.cuda.device(self.device):
+            vp = self._x3_pieces(v, None, mode)
+            mir, ws = self.mirror(3), self.workspace_bf16(rows, 1, 3, vp)
+            opts = CdOpts(1, int(mode), 0.0, 0, None, None, int(seed), 0, int(step) & 0xFFFFFFFF, int(chain))
+            if planes is not None:
+                opts.v_planes = planes.ptr(v, row_start, rows, vp)
+            out = torch.empty(4, dtype=torch.float32, device=self.device)
+            check(self.lib.kurbm_score_x3(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(), v.ptr(row_start), vp,
+                                          int(rows), v.ld, C.byref(opts), out.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                          self._stream()))
+        return out
 
     def philox_uniform(self, rows, cols, seed, stream_id, step, row0=0):
         with torch.cuda.device(self.device):

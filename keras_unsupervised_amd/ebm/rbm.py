@@ -18,6 +18,8 @@ feeds all three updates; ``'reference_sequential'`` replays the reference's thre
 ``cd_k``, ``persistent`` chains, ``seed``, data-parallel training when torch.distributed is
 initialised, ``verbose=0`` to skip the score passes.
 """
+import collections
+
 import numpy as np
 import torch
 
@@ -37,6 +39,38 @@ def _unwrap(x):
             raise ValueError("expected an array or a 1-element list of arrays")
         return x[0]
     return x
+
+
+class _ScoreRing:
+    """The per-step score of fit(verbose = 1) on its way from the device to stdout without a host synchronisation per
+    step: each score is copied (asynchronously, on the stream that computed it) into a slot of a small pinned host ring,
+    an event marks the copy, and a step's line is handed to `sink` once the step AFTER it has been queued -- by then its
+    event has normally fired, so the host stays one step ahead of the device instead of waiting for every step."""
+
+    def __init__(self, device, sink, depth=8):
+        self.cuda = torch.device(device).type == "cuda"
+        self.buf = torch.empty((depth, 4), dtype=torch.float32, pin_memory=self.cuda)
+        self.events = [torch.cuda.Event() if self.cuda else None for _ in range(depth)]
+        self.pending, self.head, self.depth, self.sink = collections.deque(), 0, depth, sink
+
+    def push(self, score_dev, label):
+        slot, self.head = self.head, (self.head + 1) % self.depth
+        self.buf[slot, :1].copy_(score_dev.reshape(-1)[:1], non_blocking=True)
+        if self.cuda:
+            self.events[slot].record()
+        self.pending.append((slot, label))
+        while len(self.pending) > 1:
+            self._pop()
+
+    def _pop(self):
+        slot, label = self.pending.popleft()
+        if self.cuda:
+            self.events[slot].synchronize()
+        self.sink(float(self.buf[slot, 0]), label)
+
+    def flush(self):
+        while self.pending:
+            self._pop()
 
 
 class RBM(object):
@@ -233,25 +267,22 @@ class RBM(object):
 
     # ------------------------------------------------------------------ training --------
     def _score(self, Vd, lo, rows, step):
-        """mean |F(v) - F(v')| with v' a fresh one-step reconstruction (rbm.py:225-233)."""
+        """mean |F(v) - F(v')| with v' a fresh one-step reconstruction (rbm.py:225-233), as a DEVICE tensor (element 0):
+        the launches are queued behind the update and nothing is read back here -- fit() prints a step's line when its
+        score has landed in pinned host memory (_ScoreRing), so the reference's default verbose = 1 costs no host
+        synchronisation per step."""
         d = self._dev
-        act_h, noise_h = hidden_site(self.mode)
-        act_v, noise_v = visible_site(self.mode)
         base = CHAIN_SCORE * CHAIN_STRIDE
         if self._large(rows):
-            # same draws, the products on the bf16 pieces
-            fe = d.free_energy(Vd, rows, lo, compute="x3")
-            h = d.half_step_bf16("vh", Vd, rows, act_h, noise_h, self.seed, base + 0, step, pieces=3, row_start=lo,
-                                 want_prob=False, want_u=False)["sample"]
-            v1 = d.half_step_bf16("hv", h, rows, act_v, noise_v, self.seed, base + 1, step, pieces=3,
-                                  want_prob=False, want_u=False)["sample"]
-            fe_p = d.free_energy(v1, rows, 0, compute="x3")
-            return float((fe - fe_p).abs().mean().item())
+            # one library call on the x3 kernels: same draws (chain CHAIN_SCORE, sites 0 and 1), products on the bf16 pieces
+            return d.score_x3(Vd, rows, lo, self.seed, step, self.mode, CHAIN_SCORE, planes=self._planes)
+        act_h, noise_h = hidden_site(self.mode)
+        act_v, noise_v = visible_site(self.mode)
         fe = d.free_energy(Vd, rows, lo)
         h = d.half_step("vh", Vd, rows, lo, act_h, noise_h, self.seed, base + 0, step)["sample"]
         v1 = d.half_step("hv", h, rows, 0, act_v, noise_v, self.seed, base + 1, step)["sample"]
         fe_p = d.free_energy(v1, rows, 0)
-        return float((fe - fe_p).abs().mean().item())
+        return (fe - fe_p).abs().mean().reshape(1)
 
     def fit(self, V, verbose=1):
         """Train the RBM on V [N, n_vis] by CD-k (rbm.py:100-234).
@@ -302,6 +333,10 @@ class RBM(object):
         # quiet single-GPU fused training (fp32 MFMA or x3): the whole batch loop of an epoch is one library call
         whole_epochs = (verbose != 1 and world == 1 and self.update_mode == "fused"
                         and self._compute() in ("fp32", "x3"))
+        def print_score(score, label):
+            self.last_scores.append(score)
+            print("\n{0:d}/{1:d}, score: {2:f}".format(label[0], label[1], score))   # rbm.py:234
+        ring = _ScoreRing(d.device, print_score) if verbose == 1 else None
         for epoch in range(int(self.hps["epochs"])):                              # rbm.py:113
             if verbose == 1:
                 print(epoch + 1, "/", self.hps["epochs"], " epochs", end="\r")   # rbm.py:115
@@ -320,9 +355,10 @@ class RBM(object):
                     self._update_data_parallel(Vd, lo, rows, lr, step, rank, world)
                 self._update_count += 1
                 if verbose == 1:
-                    score = self._score(Vd, lo, rows, step)
-                    self.last_scores.append(score)
-                    print("\n{0:d}/{1:d}, score: {2:f}".format(i + 1, num_step, score))   # rbm.py:234
+                    # (the line of step i is printed when its score has landed: at most one step late, never out of order)
+                    ring.push(self._score(Vd, lo, rows, step), (i + 1, num_step))
+            if ring is not None:
+                ring.flush()                                                     # an epoch's lines end with the epoch
         self._planes = None
         return None
 

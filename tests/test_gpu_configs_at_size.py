@@ -370,3 +370,47 @@ def test_config5_share_4096x4096_pcd10(gpu_device, compute):
                                       chain0=chain0, lr=1e-3 / 8192)
     assert flips < 22 * 16
     assert 0.02 < st["h_neg"].mean() < 0.98 and 0.02 < st["v_neg"].mean() < 0.98   # the chain is not saturated
+
+
+def test_config5_eight_shards_of_8192_rows(gpu_device):
+    """configs[4] as the eight GPUs run it: one 8192-row batch, 4096 x 4096, rounded-bf16 operands, persistent CD-10, as eight
+    1024-row shards -- shard r with row0 = r * 1024 and its own band of the fantasy particles -- each through the emit form of
+    the step (what kurbm_cd_step_bf16_dp all-reduces); the packed sums added in rank order against ONE engine running the
+    whole 8192-row batch with the same global-row draws: the same chains (ten Gibbs iterations deep, bit for bit), the same
+    integer-valued db_v, dW and db_h up to the order of the fp32 additions; then the summed update applied by two replicas
+    leaves them bit-identical.  rbm.py:119-134 (rows never interact; the updates are sums)."""
+    R, rows, nv, nh, k = 8, 1024, 4096, 4096, 10
+    B = R * rows
+    W, b_h, b_v = synthetic_params(nv, nh, seed=9)
+    W = (W * np.float32(0.25)).astype(np.float32)
+    v = synthetic_binary(B, nv, seed=10)
+    chain0 = synthetic_binary(B, nv, seed=11, p=0.5)
+    vd = _dm(v, gpu_device)
+    seed, step, lr = 42, 2, 1e-3 / B
+    total = torch.zeros(nv * nh + nh + nv, dtype=torch.float32, device=gpu_device)
+    chains = _dm(chain0, gpu_device)                     # every shard advances its own rows of ONE chain matrix
+    e = _engine(W, b_h, b_v, gpu_device)
+    for r in range(R):
+        e.cd_step(vd, rows, r * rows, lr, seed, step, k=k, apply=False, emit_delta=True, v_chain=chains, row0=r * rows,
+                  v_chain_row=r * rows, compute="bf16")
+        total += e.delta_buffer()                        # rank-ordered fp32 sum, as a ring all-reduce would add
+    one = _engine(W, b_h, b_v, gpu_device)
+    chain1 = _dm(chain0, gpu_device)
+    one.cd_step(vd, B, 0, lr, seed, step, k=k, apply=False, emit_delta=True, v_chain=chain1, compute="bf16")
+    torch.cuda.synchronize()
+    assert np.array_equal(chains.to_numpy(), chain1.to_numpy())          # same draws, same products: the same particles
+    assert 0.02 < float(chain1.view().mean().item()) < 0.98
+    dW, dbh, dbv = _split(total.cpu().numpy(), nv, nh)
+    dW1, dbh1, dbv1 = _split(one.delta_buffer().cpu().numpy(), nv, nh)
+    assert np.array_equal(dbv, dbv1)                                     # counts: exact in any order
+    assert rel_err(dbh, dbh1) <= TOL
+    scale = float(np.abs(dW1).max())
+    assert scale > 1.0 and np.max(np.abs(dW - dW1)) <= 2e-5 * scale      # order of the fp32 additions (8192-term sums)
+    # every replica applies the same total: replicas stay bit-identical, mirrors included
+    a, b = _engine(W, b_h, b_v, gpu_device), _engine(W, b_h, b_v, gpu_device)
+    for x in (a, b):
+        x.mirror(1)
+        x.apply_delta(lr, delta=total)
+    for x, y in zip(a.get_weights(), b.get_weights()):
+        assert np.array_equal(x, y)
+    assert np.max(np.abs((a.get_weights()[0] - W) - np.float32(lr) * dW)) <= 1e-6

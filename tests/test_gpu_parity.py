@@ -444,7 +444,7 @@ def test_c_abi_from_plain_c(gpu_device, tmp_path):
                     "-lm", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 3" in r.stdout
+    assert "abi 4" in r.stdout
 
 
 def test_c_abi_error_behaviour(gpu_device):
@@ -1270,3 +1270,100 @@ def test_fused_slab_reduction_is_bit_identical(gpu_device, ctx_option, cfg):
     for a, b in zip(got[1], got[0]):
         assert np.array_equal(a, b)
     assert np.all(np.isfinite(got[1][0])) and not np.array_equal(got[1][0], W0[0])
+
+
+@pytest.mark.parametrize("cfg", [dict(B=300, nv=784, nh=256, k=1, chunks=(1, 2, 3)), dict(B=260, nv=1100, nh=200, k=2, pcd=True, chunks=(1, 3)),
+                                 dict(B=256, nv=2048, nh=2048, k=1, chunks=(0, 4), auto=2), dict(B=128, nv=300, nh=150, k=1, chunks=(2,))])
+def test_bf16_dp_step_one_call(gpu_device, one_rank_comm, cfg):
+    """kurbm_cd_step_bf16_dp (the data-parallel step of BASELINE.json config 5's path): chain, statistics in row ranges of dW,
+    range i all-reduced AND applied (its rows of W, its part of the weight mirror) on the library's comm stream while range
+    i + 1 is multiplied -- against the plain sequence emit -> all-reduce -> apply.  One range: bit-identical; several: the
+    split-K slicing of a row range differs, so dW agrees to the order of the fp32 additions.  n_chunks = 0 picks by message
+    size (16.8 MB of sums -> two ranges).  n_hid % 4 != 0 takes the unfused apply.  The rewritten mirror is the new weights."""
+    B, nv, nh, k = cfg["B"], cfg["nv"], cfg["nh"], cfg["k"]
+    W0 = synthetic_params(nv, nh, seed=2300 + B)
+    V = synthetic_binary(B, nv, seed=2301 + B, p=0.3)
+    chain0 = synthetic_binary(B, nv, seed=2302 + B, p=0.5) if cfg.get("pcd") else None
+    vd = _dm(V, gpu_device)
+    ref = _engine(*W0, gpu_device)
+    cr = _dm(chain0, gpu_device) if chain0 is not None else None
+    ref.cd_step(vd, B, 0, 0.01, 5, 3, k=k, apply=False, emit_delta=True, row0=8, v_chain=cr, compute="bf16")
+    d_ref = ref.delta_buffer().clone()
+    ref.apply_delta(0.01)
+    for n_chunks in cfg["chunks"]:
+        e = _engine(*W0, gpu_device)
+        cd = _dm(chain0, gpu_device) if chain0 is not None else None
+        e.cd_step_dp(one_rank_comm, vd, B, 0, 0.01, 5, 3, k=k, row0=8, v_chain=cd, compute="bf16", n_chunks=n_chunks)
+        torch.cuda.synchronize()
+        if cd is not None:
+            assert np.array_equal(cd.to_numpy(), cr.to_numpy())
+        got, want = e.delta_buffer().cpu().numpy(), d_ref.cpu().numpy()
+        dW, dbh, dbv = _split(got, nv, nh)
+        rW, rbh, rbv = _split(want, nv, nh)
+        assert np.array_equal(dbv.view(np.uint32), rbv.view(np.uint32)) and np.array_equal(dbh.view(np.uint32), rbh.view(np.uint32))
+        if n_chunks == 1:
+            assert np.array_equal(dW.view(np.uint32), rW.view(np.uint32))
+        else:
+            assert np.max(np.abs(dW - rW)) <= 1e-4 * max(1.0, float(np.abs(rW).max()))
+        for x, y in zip(e.get_weights(), ref.get_weights()):
+            assert np.max(np.abs(x - y)) <= 1e-6 * max(1.0, float(np.abs(y).max()))
+        # the mirror the library rewrote (per range, on its comm stream) is the rounded image of the new weights
+        stale = _engine(*e.get_weights(), gpu_device)
+        p_fresh = stale.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=1)["prob"].to_numpy()
+        p_kept = e.half_step_bf16("vh", vd, B, 0, 0, 0, 0, 0, pieces=1)["prob"].to_numpy()
+        assert np.array_equal(p_fresh, p_kept)
+        h = synthetic_binary(B, nh, seed=2303 + B, p=0.5)
+        q_fresh = stale.half_step_bf16("hv", _dm(h, gpu_device), B, 0, 0, 0, 0, 0, pieces=1)["prob"].to_numpy()
+        q_kept = e.half_step_bf16("hv", _dm(h, gpu_device), B, 0, 0, 0, 0, 0, pieces=1)["prob"].to_numpy()
+        assert np.array_equal(q_fresh, q_kept)
+    # a rank that owns no rows of the batch joins with zeros
+    e = _engine(*W0, gpu_device)
+    e.cd_step_dp(one_rank_comm, vd, 0, 0, 0.01, 5, 3, k=k, compute="bf16", n_chunks=cfg["chunks"][-1])
+    torch.cuda.synchronize()
+    assert float(e.delta_buffer().abs().max().item()) == 0.0
+    for x, y in zip(e.get_weights(), W0):
+        assert np.array_equal(x, y)
+    # a refused call returns before any collective was enqueued (every check precedes the first all-reduce)
+    from keras_unsupervised_amd import _lib
+    with pytest.raises(_lib.KurbmError, match="k must be"):
+        e.cd_step_dp(one_rank_comm, vd, B, 0, 0.01, 5, 3, k=99, compute="bf16")
+    with pytest.raises(_lib.KurbmError, match="k must be"):
+        e.cd_step_dp(one_rank_comm, vd, B, 0, 0.01, 5, 3, k=99, compute="x3")
+
+
+@pytest.mark.parametrize("cfg", [dict(B=4096, nv=784, nh=1024), dict(B=4096, nv=784, nh=1024, real=True), dict(B=1024, nv=300, nh=200, gauss=True),
+                                 dict(B=1100, nv=260, nh=136), dict(B=2048, nv=784, nh=256, planes=True)])
+def test_score_one_call_vs_oracle(gpu_device, cfg):
+    """kurbm_score_x3 -- F(v), a fresh one-step reconstruction v', F(v'), mean |F - F'| into a device float, one library call,
+    no host synchronisation (rbm.py:225-233; what fit(verbose=1) prints every step) -- against the oracle's step_score with
+    the same counters; resident planes change nothing; the free energies it can also return against O.free_energy."""
+    import ctypes as C
+    from keras_unsupervised_amd._lib import CdOpts, check
+    from keras_unsupervised_amd.ebm.engine import CHAIN_SCORE
+    B, nv, nh = cfg["B"], cfg["nv"], cfg["nh"]
+    mode = O.MODE_VISIBLE_GAUSSIAN if cfg.get("gauss") else O.MODE_VISIBLE_BERNOULLI
+    W, b_h, b_v = synthetic_params(nv, nh, seed=2400 + B)
+    V = synthetic_real(B, nv, seed=2401 + B) if (cfg.get("real") or cfg.get("gauss")) else synthetic_binary(B, nv, seed=2401 + B, p=0.3)
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(V, gpu_device)
+    planes = e.make_planes(vd, [(0, B)], mode) if cfg.get("planes") else None
+    s = e.score_x3(vd, B, 0, 7, 3, mode, CHAIN_SCORE, planes=planes)
+    s2 = e.score_x3(vd, B, 0, 7, 3, mode, CHAIN_SCORE)
+    torch.cuda.synchronize()
+    got = float(s[0].item())
+    assert got == float(s2[0].item())                                  # same counters -> same draws -> same bits
+    want = O.step_score(W, b_h, b_v, V, 7, 3, mode)
+    assert abs(got - want) <= 1e-3 * max(1.0, abs(want)), (got, want)
+    # the free energies themselves (F(v) is a function of v alone; F(v') follows the reconstruction)
+    vp = e._x3_pieces(vd, None, mode)
+    mir, ws = e.mirror(3), e.workspace_bf16(B, 1, 3, vp)
+    opts = CdOpts(1, int(mode), 0.0, 0, None, None, 7, 0, 3, CHAIN_SCORE)
+    F = torch.empty(2 * B, dtype=torch.float32, device=gpu_device)
+    out = torch.empty(4, dtype=torch.float32, device=gpu_device)
+    check(e.lib.kurbm_score_x3(e.ctx.handle, C.byref(e.params), mir.data_ptr(), mir.numel(), vd.ptr(), vp, B, vd.ld, C.byref(opts),
+                               out.data_ptr(), F.data_ptr(), ws.data_ptr(), ws.numel(), e._stream()))
+    torch.cuda.synchronize()
+    Fh = F.cpu().numpy()
+    assert rel_err(Fh[:B], O.free_energy(V, W, b_h, b_v)) <= TOL
+    assert abs(float(np.mean(np.abs(Fh[:B].astype(np.float64) - Fh[B:].astype(np.float64)))) - got) <= 1e-5 * max(1.0, abs(got))
+    assert float(out[0].item()) == got
