@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_COUNT };
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
@@ -38,6 +38,8 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_X3_FUSED", 0},         // 1: the statistics GEMM reduces its own split-K slabs where its grid is resident (bit-identical to the
                                    //    separate reduce launch and no faster: 117.7 against 117.5 us per step)
     {"KURBM_DP_CHUNKS", 0},        // row ranges of dW in the data-parallel step when the caller passes n_chunks <= 0; 0: by message size
+    {"KURBM_ANYORDER", 0},         // TIMING ONLY (results race): bit 0 the half steps, bit 1 the statistics GEMM are launched without
+                                   // the AQL barrier bit -- the upper bound of what overlapping dependent launches could gain
 };
 
 struct kurbm_ctx {
@@ -786,6 +788,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.m_fastest = ctx->knob[KN_X3_MFAST];
         if (o.grid_m_out) *o.grid_m_out = ceil_div(rows, 128);   // (in 128-row units whatever the tile)
         g.xcd2d = ctx->knob[KN_X3_XCD2D];
+        g.any_order = ctx->knob[KN_ANYORDER] & 1;
         HIP_TRY(launch_gemm_pb(EPI_HALFSTEP, g, st));
         return KURBM_OK;
     }
@@ -892,8 +895,9 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     const bool f8pos = v_binary && pieces == 3 && ctx->knob[KN_X3_F8POS] != 0;
     // ... and every row-major plane of 0/1 values is a BYTE plane (half the A tile of the half step that reads it): the
     // hidden samples always, v_pos / the persistent chain for 0/1 data, the negative visibles in Bernoulli mode
-    const bool byt = pieces == 3 && ctx->knob[KN_X3_BYTES] != 0;
-    const bool hbytes = byt, vbytes = byt && v_binary, nbytes = byt && !gauss;
+    // (the rounded-bf16 path too: its 0/1 states are exact as bytes, so nothing changes but the bytes the half steps stage)
+    const bool byt = ctx->knob[KN_X3_BYTES] != 0;
+    const bool hbytes = byt, vbytes = byt && v_binary && pieces == 3, nbytes = byt && !gauss;
     int e;
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
@@ -1031,6 +1035,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
         g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
         g.xcd2d = ctx->knob[KN_X3_XCD2D];
+        g.any_order = (ctx->knob[KN_ANYORDER] >> 1) & 1;
         if (fuse) {
             g.fuse = 1; g.sync = w.sync; g.status = ctx->status; g.red = a;
             // (a launch replayed alone, kurbm_cd_step_x3_stage: no half step in front has zeroed the counters)

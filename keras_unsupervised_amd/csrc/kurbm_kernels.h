@@ -249,6 +249,7 @@ struct GemmArgsB {
     // (8 / (xcd_r xcd_c)) x xcd_r x xcd_c grid over (k slices, row tiles, column tiles); each takes one block of it, so the A
     // rows and B rows it pulls through its own L2 are a fraction of the matrix instead of all of one operand
     int xcd_r, xcd_c;
+    int any_order;        // caller: TIMING ONLY -- launch without the AQL barrier bit (ctx knob KURBM_ANYORDER); results race
     int xcd2d;            // caller: 1 = let the launcher pick such blocks (ctx knob KURBM_X3_XCD2D), 0 = the linear order
     // softplus epilogue (k_gemm_pb, free energy): rowpart[bn][row] = sum over the tile's columns of softplus(x + bias)
     float* rowpart;

@@ -32,6 +32,7 @@
 // Reference op sequences: ku/ebm/rbm.py:46-47 (v->h), :52-53 / :121-123 (h->v), :124 (h_neg), :125-134
 // (statistics); the split is an implementation choice of this build.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // One-piece tiles (the rounded-bf16 path) are 16 MFMAs per wave, shorter than the round trip of a tile's DMA: THREE
     // stages, tiles requested two ahead.  (Three-piece tiles: two stages fill the LDS.)
     constexpr int NSTG = (PB == 1) ? 3 : 2;
-    static_assert(!(AB && NSTG != 2), "A blocks: two stages");
+    // (AB: two A blocks of 128 k beside NSTG stages of B pieces; a one-piece tile of bytes -- the rounded-bf16 path's half steps
+    //  on 0/1 states -- keeps the ring of three B stages, the A blocks requested half a block per tile as with two stages)
     constexpr int STAGES_BYTES = NSTG * (A_BYTES + B_BYTES);
     constexpr int SMEM_BYTES = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
     // the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
@@ -339,7 +341,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // fragment reads are issued one step (three-piece tiles: two steps) ahead of the MFMAs that use them; the last
     // micro-step holds the tile's ONLY barrier (behind it the loaders have the next tile in the other LDS buffer), then
     // reads the NEXT tile's first fragments.
-    auto one_tile = [&](const int cur, auto npb_tag) __attribute__((always_inline)) {
+    // (cur = the tile's B stage; half = its half of the A block, AB only -- with two stages the two coincide)
+    auto one_tile = [&](const int cur, const int half, auto npb_tag) __attribute__((always_inline)) {
+        const int acur = AB ? half : cur, anext = AB ? (half ^ 1) : (cur + 1) % NSTG;
         constexpr int NPB = decltype(npb_tag)::value;
         constexpr int NU = KS * NPB;
 #ifdef KURBM_STAMPS
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 // fragments are read TWO micro-steps ahead (an LDS read under load takes longer than the 8 MFMAs
                 // of one micro-step); the tile is entered with fa[0], fb[0] loaded, so u = 0 catches up
                 if (u == 0) { frag_b(cur, 0, 1, fb[1]); frag_b(cur, 0, 2, fb[2]); }
-                if (u == 1) { frag_a(cur, 1, fa[1]); frag_b(cur, 1, 0, fb[0]); }
+                if (u == 1) { frag_a(acur, 1, fa[1]); frag_b(cur, 1, 0, fb[0]); }
                 if (u == 2) frag_b(cur, 1, 1, fb[1]);
                 if (u == 3) frag_b(cur, 1, 2, fb[2]);
 #ifndef KURBM_BARRIER_AT
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #define KURBM_NEXT_READ_AT (KURBM_BARRIER_AT == 5 ? 5 : KURBM_BARRIER_AT + 1)
 #endif
                 if (u == KURBM_NEXT_READ_AT) {
-                    frag_a((cur + 1) % NSTG, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
+                    frag_a(anext, 0, fa[0], acur);   // (AB: after the second tile of a pair comes the other block)
                     frag_b((cur + 1) % NSTG, 0, 0, fb[0]);
                 }
                 mfmas(fa[ks & 1], fb[u % 3]);
@@ -393,12 +397,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             }
             if (u + 1 < NU) {
                 const int ksn = (u + 1) / NPB, pn = (u + 1) % NPB;
-                if (pn == 0) frag_a(cur, ksn, fa[ksn & 1]);
+                if (pn == 0) frag_a(acur, ksn, fa[ksn & 1]);
                 frag_b(cur, ksn, pn, fb[(u + 1) & 1]);
             } else {
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
-                frag_a((cur + 1) % NSTG, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
+                frag_a(anext, 0, fa[0], acur);   // (AB: after the second tile of a pair comes the other block)
                 frag_b((cur + 1) % NSTG, 0, 0, fb[0]);
             }
             mfmas(fa[ks & 1], fb[u & 1]);
@@ -436,20 +440,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
-            frag_a((cur + 1) % NSTG, 0, fa[0], cur);   // (AB: after the second tile of a pair comes the other block)
+            frag_a((cur + 1) % NSTG, 0, fa[0], cur);
             frag_b((cur + 1) % NSTG, 0, 0, fb[0]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto tile_any = [&](const int cur, const TileRef& r) __attribute__((always_inline)) {
+    auto tile_any = [&](const int cur, const int half, const TileRef& r) __attribute__((always_inline)) {
 #ifdef KURBM_STAMPS
         unsigned long long tk0, tk1;
         KURBM_STAMP(tk0);
 #endif
-        if (F8 && r.f8) f8_tile(cur);
-        else if (PB >= 3 && r.npb == 3) one_tile(cur, std::integral_constant<int, 3>{});
-        else if (PB >= 2 && r.npb == 2) one_tile(cur, std::integral_constant<int, 2>{});
-        else one_tile(cur, std::integral_constant<int, 1>{});
+        if (F8 && r.f8) f8_tile(cur);   // (never with byte A planes)
+        else if (PB >= 3 && r.npb == 3) one_tile(cur, half, std::integral_constant<int, 3>{});
+        else if (PB >= 2 && r.npb == 2) one_tile(cur, half, std::integral_constant<int, 2>{});
+        else one_tile(cur, half, std::integral_constant<int, 1>{});
 #ifdef KURBM_STAMPS
         KURBM_STAMP(tk1);
         tk[(F8 && r.f8) ? 0 : (r.npb == 3 ? 2 : 1)] += tk1 - tk0;
@@ -524,7 +528,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             // raw barriers and explicit waits: `s_waitcnt` with expcnt / lgkmcnt not waited for, vmcnt in bits 3:0 and 15:14
             constexpr int VM0 = 0x0F70;
             auto vm = [](int n) constexpr { return VM0 | (n & 15) | ((n >> 4) << 14); };
-            if constexpr (AB) {
+            if constexpr (AB && NSTG == 3) {
+                // one-piece tiles of bytes: the ring of three B stages (tile i + 2 requested while tile i is multiplied, a counted
+                // vmcnt leaves its pieces in flight across the barrier) and the two A blocks of the byte planes, block (i / 2) + 1
+                // requested half a block per tile -- in FRONT of the tile's B pieces, so that the counted wait covers it
+                constexpr int NBP = NB1;   // (pieces per loader wave of one B tile)
+                TileRef ra = tile_of(t_begin);
+                ra.neg = false; ra.oa = 0u;
+                dma_part(0, ra, 3, 0);
+                if (nt > 1) { dma_part(1, tile_of(t_begin + 1), 2); __builtin_amdgcn_s_waitcnt(vm(NBP)); }
+                else __builtin_amdgcn_s_waitcnt(VM0);
+                __builtin_amdgcn_s_barrier();
+                int nb = 2;   // stage of tile i + 2
+                for (int i = 0; i < nt; ++i) {
+                    const int jb = (i >> 1) + 1;
+                    if (2 * jb < nt) {
+                        ra.oa = __builtin_amdgcn_readfirstlane(128u * (uint32_t)((t_begin >> 1) + jb));
+                        if (i & 1) dma_part(0, ra, 1, jb & 1, NA / 2, NA);
+                        else dma_part(0, ra, 1, jb & 1, 0, NA / 2);
+                    }
+                    if (i + 2 < nt) {
+                        dma_part(nb, tile_of(t_begin + i + 2), 2);
+                        __builtin_amdgcn_s_waitcnt(vm(NBP));
+                    } else {
+                        __builtin_amdgcn_s_waitcnt(VM0);
+                    }
+                    nb = nb == 2 ? 0 : nb + 1;
+                    __builtin_amdgcn_s_barrier();
+                }
+            } else if constexpr (AB) {
                 // A block j (128 k of bytes) serves tiles 2 j and 2 j + 1; while tile i is multiplied, the B pieces of tile
                 // i + 1 and HALF of block i / 2 + 1 are requested (its buffer was freed by tile 2 (i / 2) - 1)
                 TileRef ra = tile_of(t_begin);
@@ -640,21 +672,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         KURBM_STAMP(ts[1]);
         // unrolled by two: the LDS buffers alternate statically
         int i = 0;
-        if constexpr (NSTG == 3) {
-            for (; i + 2 < nt; i += 3) {
-                tile_any(0, tile_of(t_begin + i));
-                tile_any(1, tile_of(t_begin + i + 1));
-                tile_any(2, tile_of(t_begin + i + 2));
-            }
-            if (i < nt) tile_any(0, tile_of(t_begin + i));
-            if (i + 1 < nt) tile_any(1, tile_of(t_begin + i + 1));
-        } else {
-            for (; i + 1 < nt; i += 2) {
-                tile_any(0, tile_of(t_begin + i));
-                tile_any(1, tile_of(t_begin + i + 1));
+        if constexpr (NSTG == 3 && AB) {
+            // three B stages, two halves of an A block: the (stage, half) pattern repeats every six tiles
+            for (; i + 5 < nt; i += 6) {
+                tile_any(0, 0, tile_of(t_begin + i));
+                tile_any(1, 1, tile_of(t_begin + i + 1));
+                ablk ^= 1;
+                tile_any(2, 0, tile_of(t_begin + i + 2));
+                tile_any(0, 1, tile_of(t_begin + i + 3));
+                ablk ^= 1;
+                tile_any(1, 0, tile_of(t_begin + i + 4));
+                tile_any(2, 1, tile_of(t_begin + i + 5));
                 ablk ^= 1;
             }
-            if (i < nt) tile_any(0, tile_of(t_begin + i));
+            if (i < nt) tile_any(0, 0, tile_of(t_begin + i));
+            if (i + 1 < nt) { tile_any(1, 1, tile_of(t_begin + i + 1)); ablk ^= 1; }
+            if (i + 2 < nt) tile_any(2, 0, tile_of(t_begin + i + 2));
+            if (i + 3 < nt) { tile_any(0, 1, tile_of(t_begin + i + 3)); ablk ^= 1; }
+            if (i + 4 < nt) tile_any(1, 0, tile_of(t_begin + i + 4));
+        } else if constexpr (NSTG == 3) {
+            for (; i + 2 < nt; i += 3) {
+                tile_any(0, 0, tile_of(t_begin + i));
+                tile_any(1, 0, tile_of(t_begin + i + 1));
+                tile_any(2, 0, tile_of(t_begin + i + 2));
+            }
+            if (i < nt) tile_any(0, 0, tile_of(t_begin + i));
+            if (i + 1 < nt) tile_any(1, 0, tile_of(t_begin + i + 1));
+        } else {
+            for (; i + 1 < nt; i += 2) {
+                tile_any(0, 0, tile_of(t_begin + i));
+                tile_any(1, 1, tile_of(t_begin + i + 1));
+                ablk ^= 1;
+            }
+            if (i < nt) tile_any(0, 0, tile_of(t_begin + i));
         }
     }
     __syncthreads();
@@ -1083,16 +1133,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 // ------------------------------------------------------------------------------------
 // one (pieces, epilogue, noise) combination: tile configuration by g.cfg (0: 128 x 128; 2: 256 x 64, half steps only); only
 // the combinations the host plans are instantiated
+// g.any_order (experiment knob KURBM_ANYORDER, TIMING ONLY): the dispatch leaves the AQL barrier bit clear (hipExtAnyOrderLaunch),
+// so its workgroups start as CUs come free under the tail of the launch in front -- without any dependency tracking, i.e. the
+// results race.  It bounds from above what a dependency-tracking version of the same overlap (row-block flags between the half
+// steps of a chain) could gain: DESIGN.md section 4.
+#define KURBM_LAUNCH(kern, grid, block, shmem, st, g)                                                                   \
+    do {                                                                                                               \
+        if ((g).any_order) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, nullptr, nullptr, hipExtAnyOrderLaunch, g); \
+        else hipLaunchKernelGGL(kern, grid, block, shmem, st, g);                                                      \
+    } while (0)
 template <int PBN, int E, int NZ>
 static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
     if (g.a_bytes) {   // byte A planes: the half steps of the x3 path, and the free-energy GEMM of a 0/1 plane
         if constexpr (E == EPI_SOFTPLUS && PBN == 3) {
             if (g.cfg != 0) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+            KURBM_LAUNCH((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             return hipGetLastError();
-        } else if constexpr (E == EPI_HALFSTEP && PBN == 3) {
-            if (g.cfg == 2) hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
-            else if (g.cfg == 0) hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+        } else if constexpr (E == EPI_HALFSTEP) {
+            if (g.cfg == 2) KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+            else if (g.cfg == 0) KURBM_LAUNCH((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             else return hipErrorInvalidValue;
             return hipGetLastError();
         } else {
@@ -1101,10 +1160,10 @@ static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
     }
     if (g.cfg == 2) {
         if constexpr (E == EPI_HALFSTEP || (E == EPI_SLAB && PBN == 3))
-            hipLaunchKernelGGL((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ>), dim3(nblk), dim3(768), 0, st, g);
+            KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ>), dim3(nblk), dim3(768), 0, st, g);
         else return hipErrorInvalidValue;
     } else if (g.cfg == 0) {
-        hipLaunchKernelGGL((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ>), dim3(nblk), dim3(768), 0, st, g);
+        KURBM_LAUNCH((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ>), dim3(nblk), dim3(768), 0, st, g);
     } else {
         return hipErrorInvalidValue;
     }

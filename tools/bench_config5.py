@@ -23,6 +23,7 @@ ap.add_argument("--nv", type=int, default=4096)
 ap.add_argument("--nh", type=int, default=4096)
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--only", default="", help="one compute path (fp32 / x3 / bf16): for rocprofv3 --kernel-trace --stats")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 g = np.random.default_rng(1)
@@ -30,7 +31,7 @@ W = g.uniform(-0.05, 0.05, (a.nv, a.nh)).astype(np.float32)
 V = DeviceMatrix.from_host((torch.rand(a.rows, a.nv, device=dev) < 0.19).float(), dev)
 flop = (4 * a.k + 8) * a.rows * a.nv * a.nh            # persistent CD-k
 out = {"workload": "rbm_%dx%d_pcd%d_rows%d" % (a.nv, a.nh, a.k, a.rows), "flop_per_step": flop}
-for name in ("fp32", "x3", "bf16"):
+for name in ((a.only,) if a.only else ("fp32", "x3", "bf16")):
     eng = DeviceRBM(W, np.zeros(a.nh, np.float32), np.zeros(a.nv, np.float32), dev)
     chain = DeviceMatrix.from_host(V.view().clone(), dev)
     lr = 1e-3 / a.rows
