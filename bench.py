@@ -18,10 +18,12 @@ step time falls ~15 % over the first ~20 ms while the clocks ramp); `value_stead
 after 256 further untimed steps.  All three are on the line, labelled in config.timing.
 
 With N > 1 (one process per GPU, torch.distributed.run) every rank processes its own 4096 rows per step (weak scaling:
-global batch 4096 N, config 3 at N = 8) through kurbm_cd_step_x3_dp: the packed [dW|db_h|db_v] sums are all-reduced by
-RCCL inside libkurbm.so, in row ranges overlapped with the statistics GEMM.  torch.distributed (gloo) only carries the
-RCCL unique id and the max-over-ranks of the block times; the barriers are all-reduces on the RCCL communicator itself.
-`rccl_ranks` is ncclCommCount's answer.
+global batch 4096 N, config 3 at N = 8) through kurbm_cd_step_x3_dp: the packed [dW|db_h|db_v] sums (3.2 MB) are all-reduced
+by RCCL inside libkurbm.so -- one range on the launch stream at this size.  torch.distributed (gloo)
+only carries the RCCL unique id and the max-over-ranks of the block times; the barriers are all-reduces on the RCCL
+communicator itself.  `rccl_ranks` is ncclCommCount's answer.  UNVERIFIED ON HARDWARE: no box with more than one GPU has been
+available to this build, so the N > 1 path has run only at world size 1 (BENCH_FORCE_DP=1), on CPU doubles at world size 2
+(tests/test_dp_gloo.py), and in tests/test_two_gpus.py nowhere yet.
 
 The line also carries `roofline` (dominant kernel, HIP-event timed on the launch stream, and the whole step) and
 `cpu_baseline` (oracle/cpu_baseline.py: the same op sequence on torch-CPU over all host cores; rank 0, N = 1 only).
@@ -33,6 +35,9 @@ import os
 import statistics
 import sys
 import time
+
+# (RCCL / device-memory sharing across the processes of a node needs dmabuf IPC on this stack; the GPU boxes export it already)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -236,14 +241,17 @@ def main():
                                                                       planes=plg), X3_UNITS["gaussian_real"])
             paths["gaussian_default_mode_fp32"] = path(lambda: eng.cd_step(Vg, BATCH, 0, lr, seed, 0, mode=MODE_VISIBLE_GAUSSIAN, compute="fp32"))
             eng.set_weights(*Wkeep)
-        traffic_all, traffic_file = {}, None
+        traffic_all, traffic_file, pmc_all, pmc_file = {}, None, {}, None
         try:
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
                 traffic_all.update(json.load(open(f)))      # later files win
                 traffic_file = os.path.relpath(f, ROOT)
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_x3_gemm.json"))):
+                pmc_all.update(json.load(open(f)))
+                pmc_file = os.path.relpath(f, ROOT)
         except Exception:
-            traffic_all = {}
+            traffic_all, pmc_all = {}, {}
         if args.compute == "x3":
             dom = max(x3_units, key=lambda k: kern_x3[k]["ms"])
             step16, step8 = (12, 1) if f8pos else (13, 0)
@@ -256,6 +264,10 @@ def main():
                                 "take at the dense peaks of their types (bf16 2.5, fp8 5.0 PFLOP/s), frac = that time / the duration",
                         "traffic": traffic_all.get(dom, {}).get("hbm_bytes_per_launch"),
                         "traffic_source": "%s (rocprofv3 --pmc passes of an earlier run of this command; not measured in this run)" % traffic_file,
+                        "mfma_busy": pmc_all.get(dom, {}).get("mfma_busy_share"),
+                        "wait_any": pmc_all.get(dom, {}).get("wait_any_share"),
+                        "l2_hit_rate": pmc_all.get(dom, {}).get("l2_hit_rate"),
+                        "counters_source": "%s (SQ / TCC counter passes of tools/round3_profile.sh on the same kernels; not measured in this run)" % pmc_file,
                         "step": {"executed_tflops": X3_UNITS["binary"] * BVH2 / (ms_per_step * 1e-3) / 1e12 * world,
                                  "frac": mfma_roof_ms(step16, step8) / ms_per_step,
                                  "note": "all 13 GEMM units of a step (%d bf16 + %d fp8): the time their MFMAs take at the dense peaks "

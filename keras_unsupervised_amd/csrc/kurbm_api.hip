@@ -739,6 +739,8 @@ struct HalfOutB {
     float colsign = 1.f;                                  // x3: colpart = colsign * column sums of the value plane
     int* grid_m_out = nullptr;
     unsigned* zero_words = nullptr; int n_zero = 0;       // words this launch zeroes (the next launch's arrival counters)
+    float* rowpart = nullptr; int ld_rowpart = 0;         // x3, Bernoulli draws: softplus row sums of the tile's columns (the score)
+    int* grid_n_out = nullptr;                            // ... and how many column tiles wrote them
 };
 
 // one half step: A [rows][lda] bf16 in a_pieces pieces (k padded), weights from the mirror
@@ -783,6 +785,10 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
         g.colpart = o.colpart; g.ld_colpart = o.ld_colpart; g.colsign = o.colsign;
         g.zero_words = o.zero_words; g.n_zero = o.n_zero;
+        if (o.rowpart) {
+            g.rowpart = o.rowpart; g.ld_rowpart = o.ld_rowpart; g.rp = 1;
+            if (o.grid_n_out) *o.grid_n_out = ceil_div(g.N, g.cfg == 2 ? 64 : 128);   // (tiles in the column padding write zeros)
+        }
         // row tiles fastest: an XCD's run of workgroups then shares ONE column tile, whose weight pieces
         // (the operand loaded straight into registers, one tile ahead) stay in that XCD's L2
         g.m_fastest = ctx->knob[KN_X3_MFAST];
@@ -1168,9 +1174,9 @@ int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
 int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* v_batch, int v_pieces,
                    int rows, int ldv, const kurbm_cd_opts* o, float* score, float* F, void* workspace, size_t workspace_bytes,
                    kurbm_stream_t stream) {
-    // rbm.py:225-233 in one call, nothing returned to the host: F(v) [GEMM + softplus row sums on the planes of v], h ~ p(h | v)
-    // [half step], v' ~ p(v | h) [half step; its row-major plane feeds the next GEMM, an fp32 copy the v'.b_v term], F(v'),
-    // then |F - F'| per row and its mean into *score.  Draws: chain o->chain, sites 0 (h) and 1 (v'), step o->step -- the
+    // rbm.py:225-233 in one call, nothing returned to the host: h ~ p(h | v) [half step, which also leaves the softplus row sums
+    // of F(v): same accumulators], v' ~ p(v | h) [half step; its row-major plane feeds the next GEMM, an fp32 copy the v'.b_v
+    // term], F(v') [GEMM + softplus row sums], then |F - F'| per row and its mean into *score.  Draws: chain o->chain, sites 0 (h) and 1 (v'), step o->step -- the
     // counters RBM._score has always used.
     if (!score || !aligned16(score)) return fail(KURBM_ERR_ARG, "score is null or misaligned");
     if (int e = check_cd_args(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, o, workspace, workspace_bytes, false)) return e;
@@ -1185,10 +1191,11 @@ int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t m
     const bool f8pos = v_binary && ctx->knob[KN_X3_F8POS] != 0;      // (only so that a conversion here writes what a step would)
     const int vn_pieces = gauss ? 3 : 1;
     const uint32_t base = o->chain * 64u;
-    // row partials of the two free-energy GEMMs live in the (unused here) slab area; |F - F'| per row behind them
-    const int ncol = ceil_div(p->n_hid, 128), ld_rp = round_up(rows, 4);
-    if ((size_t)(2 * ncol + 1) * ld_rp > w.slab_stride) return fail(KURBM_ERR_WORKSPACE, "workspace too small for the score's row partials");
-    float* rp0 = w.slab; float* rp1 = w.slab + (size_t)ncol * ld_rp; float* absdiff = w.slab + (size_t)2 * ncol * ld_rp;
+    // row partials of the two free energies live in the (unused here) slab area; |F - F'| per row behind them
+    const int ncol = ceil_div(p->n_hid, 128), ncol_max = ceil_div(p->n_hid, 64), ld_rp = round_up(rows, 4);   // (tiles of 128 / of 64 columns)
+    if ((size_t)(2 * ncol_max + 1) * ld_rp > w.slab_stride) return fail(KURBM_ERR_WORKSPACE, "workspace too small for the score's row partials");
+    float* rp0 = w.slab; float* rp1 = w.slab + (size_t)ncol_max * ld_rp; float* absdiff = rp1 + (size_t)ncol_max * ld_rp;
+    if (!aligned16(p->b_v)) return fail(KURBM_ERR_ARG, "b_v must be 16-byte aligned for the score");
     if (o->v_planes) {
         const VPlanes vp = carve_vplanes(ctx, o->v_planes, rows, p->n_vis, v_pieces);
         w.vb = vp.vb;
@@ -1197,30 +1204,14 @@ int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t m
                                    0, vbytes ? 1 : 0));
     }
     (void)f8pos;
-    auto softplus_gemm = [&](const uint16_t* A, int a_pieces, bool a_bytes, float* rowpart) -> int {
-        GemmArgsB g;
-        memset(&g, 0, sizeof g);
-        g.A0 = A; g.lda = w.Lv; g.a_plane0 = w.planeV; g.a_bytes = a_bytes ? 1 : 0;
-        g.B0 = m.Wtb; g.ldb = m.ldWt; g.b_plane0 = m.planeWt;
-        g.M = rows; g.N = p->n_hid; g.K = round_up(p->n_vis, 64);
-        g.grid_m = ceil_div(rows, 128); g.grid_n = ncol;
-        g.nseg = pb_codes(ctx, a_pieces, 3, 0u, &g.seg_codes, 0);
-        g.pb_max = 3;
-        g.nkt = g.K / 64; g.inv_nkt = inv_of(g.nkt);
-        g.kt_total = g.nseg * g.nkt; g.kt_per_split = g.kt_total; g.nsplit = 1;
-        g.m_fastest = 1;
-        g.bias = p->b_h;
-        g.rowpart = rowpart; g.ld_rowpart = ld_rp;
-        g.xcd2d = ctx->knob[KN_X3_XCD2D];
-        HIP_TRY(launch_gemm_pb(EPI_SOFTPLUS, g, st));
-        return KURBM_OK;
-    };
     int e;
-    if ((e = softplus_gemm(w.vb, v_pieces, vbytes, rp0))) return e;                                   // F(v)      rbm.py:227
+    int ncol0 = ncol;
     RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
     {
+        // h ~ p(h | v) AND the softplus row sums of F(v), from the same accumulators: one GEMM for rbm.py:227 and :230
         HalfOutB ho;
         ho.out = w.hb; ho.ldo = w.Lh; ho.out_bytes = hbytes;
+        ho.rowpart = rp0; ho.ld_rowpart = ld_rp; ho.grid_n_out = &ncol0;
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Lv, v_pieces, w.planeV, rows, gauss ? ACT_RELU : ACT_SIGMOID, NOISE_BERNOULLI,
                              &r, ho, st, vbytes))) return e;                                            // h          rbm.py:230
     }
@@ -1232,10 +1223,16 @@ int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t m
         if ((e = half_step_b(ctx, LAYOUT_HV, p, m, w.hb, w.Lh, 1, 0, rows, gauss ? ACT_LINEAR : ACT_SIGMOID,
                              gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, &r, ho, st, hbytes))) return e;   // v'
     }
-    if ((e = softplus_gemm(w.v2b, vn_pieces, nbytes, rp1))) return e;                                 // F(v')     rbm.py:231
+    int ncol1 = ncol;
+    {
+        // F(v'): the same GEMM as a half step that draws nothing and stores nothing but its softplus row sums     rbm.py:231
+        HalfOutB ho;
+        ho.rowpart = rp1; ho.ld_rowpart = ld_rp; ho.grid_n_out = &ncol1;
+        if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st, nbytes))) return e;
+    }
     ScoreArgs a;
     a.v = v_batch; a.v1 = w.tmp32; a.b_v = p->b_v; a.rowpart = rp0; a.rowpart1 = rp1; a.F = F; a.absdiff = absdiff; a.score = score;
-    a.rows = rows; a.n_vis = p->n_vis; a.ldv = ldv; a.ldv1 = w.ldv32; a.ncol_tiles = ncol; a.ld_rowpart = ld_rp;
+    a.rows = rows; a.n_vis = p->n_vis; a.ldv = ldv; a.ldv1 = w.ldv32; a.ncol_tiles = ncol0; a.ncol_tiles1 = ncol1; a.ld_rowpart = ld_rp;
     HIP_TRY(launch_score(a, st));                                                                      // mean |F - F'|  rbm.py:233
     return KURBM_OK;
 }

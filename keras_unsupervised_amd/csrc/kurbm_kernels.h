@@ -165,7 +165,7 @@ struct ScoreArgs {
     float* F;              // nullable [2 * rows]: F(v) then F(v')
     float* absdiff;        // [rows]
     float* score;          // [1]
-    int rows, n_vis, ldv, ldv1, ncol_tiles, ld_rowpart;
+    int rows, n_vis, ldv, ldv1, ncol_tiles, ncol_tiles1, ld_rowpart;   // (column tiles of v's partials, of v''s)
 };
 hipError_t launch_score(const ScoreArgs& a, hipStream_t st);
 
@@ -254,6 +254,7 @@ struct GemmArgsB {
     // softplus epilogue (k_gemm_pb, free energy): rowpart[bn][row] = sum over the tile's columns of softplus(x + bias)
     float* rowpart;
     int ld_rowpart;
+    int rp;               // EPI_HALFSTEP (Bernoulli draws, x3): 1 = also write those row partials (k_gemm_pb<..., RP>)
     // EPI_SLAB with fuse != 0: the statistics GEMM reduces its own split-K slabs (kurbm_x3.hip, "fused reduction"): `red`
     // names W, lr, the weight-piece mirror and the bias partials exactly as the separate launch (k_reduce_apply_split) takes
     // them; `sync` = one arrival counter per output tile [grid_m * grid_n], ZERO when the launch starts (the half step in

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
                             sm = (ua < p) ? 1.0f : 0.0f;
                         } else if (NOISE == NOISE_GAUSSIAN) {
                             const float ub = u32_to_unit(w2[r]);
-                            sm = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * ub);
+                            sm = p + box_muller(ua, ub);
                         }
                         pv[mi][ni][r] = p; sv[mi][ni][r] = sm; uv[mi][ni][r] = ua;
                     }
@@ -717,13 +717,10 @@ __global__ __launch_bounds__(256) void k_free_energy_finish(FinishArgs a) {
     if (row >= a.rows) return;
     float t = 0.f;
     for (int c = lane; c < a.n_vis; c += 64) t += a.v[(size_t)row * a.ldv + c] * a.b_v[c];
+    for (int i = lane; i < a.ncol_tiles; i += 64) t += a.rowpart[(size_t)i * a.ld_rowpart + row];   // (one partial per lane)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    if (lane == 0) {
-        float sp = 0.f;
-        for (int i = 0; i < a.ncol_tiles; ++i) sp += a.rowpart[(size_t)i * a.ld_rowpart + row];
-        a.F[row] = -(t + sp);
-    }
+    if (lane == 0) a.F[row] = -t;
 }
 
 // The score of fit(verbose = 1) (rbm.py:225-233).  One wave per row: F(v) = -(v.b_v + its softplus partials), the same for
@@ -733,21 +730,40 @@ __global__ __launch_bounds__(256) void k_score_rows(ScoreArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
     if (row >= a.rows) return;
+    // v.b_v and v'.b_v: 16-byte loads, all of a row's in flight at once (rows are 16-byte aligned, ld % 4 == 0)
+    const int n4 = a.n_vis >> 2;
+    const float* vr = a.v + (size_t)row * a.ldv;
+    const float* v1r = a.v1 + (size_t)row * a.ldv1;
     float t = 0.f, t1 = 0.f;
-    for (int c = lane; c < a.n_vis; c += 64) {
-        const float b = a.b_v[c];
-        t += a.v[(size_t)row * a.ldv + c] * b;
-        t1 += a.v1[(size_t)row * a.ldv1 + c] * b;
+    for (int c0 = 0; c0 < n4; c0 += 256) {
+        f32x4 x[4], y[4], b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e * 64 + lane;
+            const bool ok = c < n4;
+            x[e] = ok ? *reinterpret_cast<const f32x4*>(vr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            y[e] = ok ? *reinterpret_cast<const f32x4*>(v1r + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            b[e] = ok ? *reinterpret_cast<const f32x4*>(a.b_v + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t += x[e].x * b[e].x + x[e].y * b[e].y + x[e].z * b[e].z + x[e].w * b[e].w;
+            t1 += y[e].x * b[e].x + y[e].y * b[e].y + y[e].z * b[e].z + y[e].w * b[e].w;
+        }
     }
+    for (int c = 4 * n4 + lane; c < a.n_vis; c += 64) {      // (n_vis % 4 columns)
+        const float b = a.b_v[c];
+        t += vr[c] * b;
+        t1 += v1r[c] * b;
+    }
+    // the softplus partials of the row's column tiles join the same reduction, one per lane (a single lane walking 2 x 16
+    // partials in dependent loads was the longest chain of this launch)
+    for (int i = lane; i < a.ncol_tiles; i += 64) t += a.rowpart[(size_t)i * a.ld_rowpart + row];
+    for (int i = lane; i < a.ncol_tiles1; i += 64) t1 += a.rowpart1[(size_t)i * a.ld_rowpart + row];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); t1 += __shfl_xor(t1, o); }
     if (lane == 0) {
-        float sp = 0.f, sp1 = 0.f;
-        for (int i = 0; i < a.ncol_tiles; ++i) {
-            sp += a.rowpart[(size_t)i * a.ld_rowpart + row];
-            sp1 += a.rowpart1[(size_t)i * a.ld_rowpart + row];
-        }
-        const float F = -(t + sp), F1 = -(t1 + sp1);
+        const float F = -t, F1 = -t1;
         if (a.F) { a.F[row] = F; a.F[a.rows + row] = F1; }
         a.absdiff[row] = fabsf(F - F1);
     }

@@ -92,7 +92,10 @@ __device__ __forceinline__ FuseRows fuse_rows(const GemmArgsB& g, int m0, int z)
 // BOTH k-steps of a tile are one ds_read_b128 -- the very chunk / swizzle / bank pattern of the bf16 fragments (two
 // 8-byte reads per tile fused into ds_read2_b64 and cost 27 % of the LDS cycles in bank conflicts).  The MFMA waves
 // expand a k-step's 8 bytes with four v_perm_b32.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int PB, int EPI, int NOISE, bool AB = false>
+// RP: a half step that ALSO leaves the row sums of softplus(x + bias) over each tile's columns in g.rowpart [column tiles][rows]
+// -- the free energy F(v) (rbm.py:73-75) of the rows whose hidden states it samples, from the same accumulators: the score of
+// fit(verbose = 1) then needs three GEMMs, not four (kurbm_score_x3).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int PB, int EPI, int NOISE, bool AB = false, bool RP = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES_N + 256) / 256) void k_gemm_pb(GemmArgsB g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;          // threads of the MFMA waves (and of every epilogue loop)
     constexpr int NTS = 256;                            // threads of the loader waves
@@ -637,9 +640,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 for (int r0 = fr.lo; r0 < fr.hi; r0 += FUSE_RC) { __syncthreads(); __syncthreads(); }
             }
         } else if (EPI == EPI_SLAB || EPI == EPI_SOFTPLUS) __syncthreads();
-        else if (g.out) {
-            const int nb = (g.out_pieces == 3) ? 5 : 1;
-            for (int q = 0; q < nb; ++q) __syncthreads();
+        else {
+            if (RP) { __syncthreads(); __syncthreads(); }   // (the row partials' trip through LDS)
+            if (g.out) {
+                const int nb = (g.out_pieces == 3) ? 5 : 1;
+                for (int q = 0; q < nb; ++q) __syncthreads();
+            }
         }
         return;
     }
@@ -895,6 +901,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     }
 
     // ---------------- epilogue of a half step ------------------------------------------------
+    if constexpr (RP) {
+        // row sums of softplus(pre-activation) over the tile's columns, as the free-energy GEMM's epilogue forms them
+        float rsum[TM][4];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rsum[mi][r] = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const bool cok = n0 + wn * WN + ni * 16 + l15 < g.N;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (cok) rsum[mi][r] += softplusf((AB ? 0.5f * acc[mi][ni][r] : acc[mi][ni][r]) + biasv[ni]);
+        }
+        float* red = reinterpret_cast<float*>(smem);   // [WAVES_N][BM]: the stages are free behind the k loop's last barrier
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = rsum[mi][r];
+                t += __shfl_xor(t, 1);
+                t += __shfl_xor(t, 2);
+                t += __shfl_xor(t, 4);
+                t += __shfl_xor(t, 8);
+                if (l15 == 0) red[wn * BM + wm * WM + mi * 16 + slot * 4 + r] = t;
+            }
+        __syncthreads();
+        if (tid < BM && g.rowpart) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < WAVES_N; ++i) t += red[i * BM + tid];
+            if (m0 + tid < g.M) g.rowpart[(size_t)bn * g.ld_rowpart + m0 + tid] = t;
+        }
+        __syncthreads();                               // (the plane patches reuse this LDS)
+    }
     float xv[TM][TN][4];   // the value plane: the sample, or the probability when nothing is drawn
     int colb = n0 + wn * WN + l15;
     asm volatile("" : "+v"(colb));   // opaque: keeps the epilogue's address arithmetic out of the k loop's registers
@@ -945,7 +988,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                         else p = x;
                         const float ua = (NOISE != NOISE_NONE) ? u32_to_unit(w[r]) : 0.f;
                         if (NOISE == NOISE_GAUSSIAN)   // N(p, 1) by Box-Muller from the site's two planes (oracle/philox.py normal())
-                            xv[mi][ni][r] = p + sqrtf(-2.0f * logf(1.0f - ua)) * cospif(2.0f * u32_to_unit(w2[r]));
+                            xv[mi][ni][r] = p + box_muller(ua, u32_to_unit(w2[r]));
                         else
                             xv[mi][ni][r] = (NOISE == NOISE_BERNOULLI) ? ((ua < p) ? 1.0f : 0.0f) : p;
                         // (Gaussian: the run-time test stays -- 32 Box-Muller chains in flight at once spill)
@@ -1144,6 +1187,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     } while (0)
 template <int PBN, int E, int NZ>
 static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
+    if constexpr (E == EPI_HALFSTEP && PBN == 3 && (NZ == NOISE_BERNOULLI || NZ == NOISE_NONE)) {
+        if (g.rp) {   // the score's half steps: (samples AND) the softplus row sums of their rows
+            if (!g.rowpart) return hipErrorInvalidValue;
+            if (g.cfg == 2 && g.a_bytes) KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true, true>), dim3(nblk), dim3(768), 0, st, g);
+            else if (g.cfg == 2) KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, false, true>), dim3(nblk), dim3(768), 0, st, g);
+            else if (g.cfg == 0 && g.a_bytes) KURBM_LAUNCH((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true, true>), dim3(nblk), dim3(768), 0, st, g);
+            else if (g.cfg == 0) KURBM_LAUNCH((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, false, true>), dim3(nblk), dim3(768), 0, st, g);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+    }
     if (g.a_bytes) {   // byte A planes: the half steps of the x3 path, and the free-energy GEMM of a 0/1 plane
         if constexpr (E == EPI_SOFTPLUS && PBN == 3) {
             if (g.cfg != 0) return hipErrorInvalidValue;
