@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     [[maybe_unused]] const rsrc_t dB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.baseB), 0, 0xFFFFFFFF, 0x00020000);
 
     // a tile: the scalar byte offsets of its A rows and of piece 0 of its B rows
-    struct TileRef { uint32_t oa, ob, bplane; int npb; bool neg, f8; };
+    struct TileRef { uint32_t oa, ob, bplane, oa_piece; int npb; bool neg, f8; };
     constexpr bool F8 = (EPI == EPI_SLAB && PB == 3);   // the kernel that may meet fp8 tiles (g.f8pos)
     auto tile_of = [&](int t) __attribute__((always_inline)) {
         TileRef r;
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         const bool neg = (code & 16u) != 0u;
         const uint32_t k0 = 2u * (uint32_t)(kt * BKB);   // (128 bytes per k-tile, bf16 or fp8)
         r.oa = __builtin_amdgcn_readfirstlane(2u * (code & 3u) * (uint32_t)(neg ? g.a_plane1 : g.a_plane0) + k0);   // (AB: unused)
+        r.oa_piece = __builtin_amdgcn_readfirstlane(code & 3u);   // (diagnostic builds)
         r.neg = __builtin_amdgcn_readfirstlane((int)neg) != 0;
         r.f8 = __builtin_amdgcn_readfirstlane((int)f8) != 0;
         r.ob = __builtin_amdgcn_readfirstlane((neg ? g.offB1 : g.offB0) + k0);
@@ -496,6 +497,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             auto dma_part = [&](int buf, const TileRef& r, int part, int ablk_ = 0, int a_lo = 0, int a_hi = 1 << 20) __attribute__((always_inline)) {
 #if defined(KURBM_ABLATE) && (KURBM_ABLATE & 1)
                 return;   // timing-only build: no global loads
+#endif
+#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 8)
+                // timing-only build: the tiles of the SECOND and THIRD piece of a real-valued A operand keep the A tile that is
+                // in LDS (garbage results) -- 44 % fewer staged bytes per k position at the same tile and MFMA count: does the
+                // loop follow the bytes or the number of tiles?  
+                if (!AB && (r.oa_piece != 0u)) part &= ~1;
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass drops a kernel's launch stub over the LDS address-space cast)
                 typedef __attribute__((address_space(3))) void* lds_ptr;
