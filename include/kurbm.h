@@ -282,6 +282,14 @@ int kurbm_cd_step_x3_stage(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, 
                            int which, int stage, void* workspace, size_t workspace_bytes,
                            kurbm_stream_t stream);
 
+/* Test hook: the planes the last complete kurbm_cd_step_x3 (same rows, v_pieces, opts->mode; CD-1, no persistent chain) left
+ * in `workspace`, decoded to fp32 [rows][units] -- bytes (0x40 = one, k-permuted), fp8 (0x38 = one), bf16, or the sum of
+ * three bf16 pieces; transposed planes are transposed back, the negated h_neg plane is un-negated.  The tests compare them
+ * with the states the half-step hooks return for the same counters, i.e. with the oracle. */
+enum { KURBM_PLANE_H_POS = 0, KURBM_PLANE_H_POS_T = 1, KURBM_PLANE_V_NEG = 2, KURBM_PLANE_V_NEG_T = 3, KURBM_PLANE_H_NEG_T = 4 };
+int kurbm_x3_dump_plane(kurbm_ctx* ctx, int which, int rows, int n_vis, int n_hid, int v_pieces, int mode,
+                        const void* workspace, size_t workspace_bytes, float* out, int ld_out, kurbm_stream_t stream);
+
 /* The per-step score of fit(verbose = 1), rbm.py:225-233, on the x3 path in ONE call with nothing returned to the host:
  * fe = F(v_batch); v' = a one-step reconstruction of v_batch (fresh chain: opts->chain, sites 0 and 1, opts->step, opts->seed,
  * opts->row0, opts->mode; opts->v_planes as for a step); fe' = F(v'); *score = mean |fe - fe'| (device float, 16-byte

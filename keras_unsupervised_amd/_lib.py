@@ -71,6 +71,7 @@ SIGNATURES = {
     "kurbm_cd_step_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _vp, _sz, _vp]),
     "kurbm_cd_step_x3_stage": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _i, _vp, _sz, _vp]),
     "kurbm_free_energy_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "kurbm_x3_dump_plane": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
     "kurbm_score_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _vp, _vp, _vp, _sz, _vp]),
     "kurbm_cd_epoch_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _i, _OP, _vp, _sz, _vp]),
     "kurbm_cd_chain_x3": (_i, [_vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _vp, _sz, _vp]),
@@ -93,6 +94,7 @@ SIGNATURES = {
 
 ABI_VERSION = 4
 V_BINARY = 0x10          # KURBM_V_BINARY: OR into v_pieces = 1 for 0/1 data
+PLANE_H_POS, PLANE_H_POS_T, PLANE_V_NEG, PLANE_V_NEG_T, PLANE_H_NEG_T = range(5)   # kurbm_x3_dump_plane
 UNIQUE_ID_BYTES = 128
 
 _lib = None

@@ -1237,6 +1237,36 @@ int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t m
     return KURBM_OK;
 }
 
+int kurbm_x3_dump_plane(kurbm_ctx* ctx, int which, int rows, int n_vis, int n_hid, int v_pieces, int mode, const void* workspace,
+                        size_t workspace_bytes, float* out, int ld_out, kurbm_stream_t stream) {
+    // the planes the last complete kurbm_cd_step_x3 on (rows, v_pieces, mode) left in `workspace`, decoded to fp32 [rows][units]
+    if (!ctx || !workspace || !out) return fail(KURBM_ERR_ARG, "null argument");
+    const bool v_binary = (v_pieces == (1 | KURBM_V_BINARY));
+    if (v_binary) v_pieces = 1;
+    if (rows <= 0 || n_vis <= 0 || n_hid <= 0 || (v_pieces != 1 && v_pieces != 3)) return fail(KURBM_ERR_ARG, "bad shape / v_pieces");
+    const WorkspaceB w = carve_bf16(ctx, const_cast<void*>(workspace), rows, n_vis, n_hid, 3, v_pieces);
+    if (w.bytes > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small");
+    const bool gauss = (mode == KURBM_MODE_VISIBLE_GAUSSIAN), byt = ctx->knob[KN_X3_BYTES] != 0;
+    const bool f8pos = v_binary && ctx->knob[KN_X3_F8POS] != 0;
+    DumpArgs a;
+    memset(&a, 0, sizeof a);
+    a.out = out; a.rows = rows; a.ld_out = ld_out; a.pieces = 1; a.sign = 1.f;
+    switch (which) {
+        case KURBM_PLANE_H_POS:   a.src = w.hb;   a.units = n_hid; a.ld = w.Lh; a.fmt = byt ? 1 : 0; break;
+        case KURBM_PLANE_H_POS_T: a.src = w.hbT;  a.units = n_hid; a.ld = w.Lb; a.fmt = f8pos ? 2 : 0; a.transposed = 1; break;
+        case KURBM_PLANE_V_NEG:   a.src = w.v2b;  a.units = n_vis; a.ld = w.Lv; a.fmt = (byt && !gauss) ? 1 : 0;
+                                  a.pieces = gauss ? 3 : 1; a.plane = w.planeV; break;
+        case KURBM_PLANE_V_NEG_T: a.src = w.v2bT; a.units = n_vis; a.ld = w.Lb; a.transposed = 1;
+                                  a.pieces = gauss ? 3 : 1; a.plane = w.planeVT; break;
+        case KURBM_PLANE_H_NEG_T: a.src = w.hnT;  a.units = n_hid; a.ld = w.Lb; a.transposed = 1; a.pieces = 3; a.plane = w.planeHT;
+                                  a.sign = -1.f; break;
+        default: return fail(KURBM_ERR_ARG, "unknown plane %d", which);
+    }
+    if (ld_out < a.units) return fail(KURBM_ERR_ARG, "ld_out < units");
+    HIP_TRY(launch_dump_plane(a, static_cast<hipStream_t>(stream)));
+    return KURBM_OK;
+}
+
 int kurbm_cd_epoch_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t mirror_bytes, const float* V,
                       int v_pieces, int n_rows, int ldv, int batch_size, const kurbm_cd_opts* opts, void* workspace,
                       size_t workspace_bytes, kurbm_stream_t stream) {

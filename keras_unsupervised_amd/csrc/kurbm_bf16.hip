@@ -225,6 +225,33 @@ __global__ __launch_bounds__(256) void k_bf16_exact_check(const float* __restric
     if (bits) atomicOr(flag, bits);
 }
 
+// test hook: one element per thread, no attempt at speed (kurbm_kernels.h: DumpArgs)
+__global__ __launch_bounds__(256) void k_dump_plane(DumpArgs a) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long long)a.rows * a.units) return;
+    const int r = (int)(q / a.units), u = (int)(q - (long long)r * a.units);
+    const int major = a.transposed ? u : r, minor = a.transposed ? r : u;
+    float v = 0.f;
+    if (a.fmt == 0) {
+        const uint16_t* s = static_cast<const uint16_t*>(a.src);
+        for (int j = 0; j < a.pieces; ++j) v += bf16_bits_to_f32(s[(size_t)j * a.plane + (size_t)major * a.ld + minor]);
+    } else if (a.fmt == 1) {
+        const unsigned char b = static_cast<const unsigned char*>(a.src)[(size_t)major * a.ld + kperm64(minor)];
+        v = (b == 0x40) ? 1.f : (b == 0 ? 0.f : __int_as_float(0x7FC00000));      // anything else is not a plane byte: NaN
+    } else {
+        // (a transposed fp8 plane keeps the bf16 plane's row stride, 2 ld bytes: kurbm_x3.hip outT_f8)
+        const unsigned char b = static_cast<const unsigned char*>(a.src)[(size_t)major * a.ld * 2 + minor];
+        v = (b == 0x38) ? 1.f : (b == 0 ? 0.f : __int_as_float(0x7FC00000));
+    }
+    a.out[(size_t)r * a.ld_out + u] = a.sign * v;
+}
+
+hipError_t launch_dump_plane(const DumpArgs& a, hipStream_t st) {
+    const long long n = (long long)a.rows * a.units;
+    hipLaunchKernelGGL(k_dump_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------

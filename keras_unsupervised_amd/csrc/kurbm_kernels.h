@@ -270,6 +270,19 @@ struct GemmArgsB {
     unsigned long long* stamps;
 };
 
+// Test hook (kurbm_x3_dump_plane): decode one of the planes a bf16 / x3 step keeps in its workspace back to fp32 [rows][units].
+// fmt: 0 bf16, 1 bytes (0x40 = one, k-permuted in groups of 64: kperm64), 2 fp8 e4m3 (0x38 = one; 0/1 planes only).
+// transposed: the plane is [units][ld] (k = batch rows) instead of [rows][ld].  pieces > 1: the sum of `pieces` bf16 planes
+// `plane` elements apart (hi + mid + lo, exact in fp32).  sign: -1 for planes stored negated (h_neg).
+struct DumpArgs {
+    const void* src;
+    float* out;
+    int rows, units, ld, ld_out, fmt, transposed, pieces;
+    size_t plane;
+    float sign;
+};
+hipError_t launch_dump_plane(const DumpArgs& a, hipStream_t st);
+
 unsigned long long* get_stamp_buffer();
 void tile_shape(int cfg, int* bm, int* bn);
 hipError_t launch_gemm_pb(int epi, const GemmArgsB& g, hipStream_t st);

@@ -491,6 +491,18 @@ class DeviceRBM:
                                           self._stream()))
         return out
 
+    def dump_plane(self, which, v, rows, mode=MODE_VISIBLE_BERNOULLI):
+        """Test hook: one of the planes the last complete x3 CD-1 step on `rows` rows of v left in the workspace, as fp32
+        [rows, units] (which: _lib.PLANE_*)."""
+        with torch.cuda.device(self.device):
+            vp = self._x3_pieces(v, None, mode)
+            ws = self.workspace_bf16(rows, 1, 3, vp)
+            units = self.n_vis if which in (_lib.PLANE_V_NEG, _lib.PLANE_V_NEG_T) else self.n_hid
+            out = DeviceMatrix.zeros(rows, units, self.device)
+            check(self.lib.kurbm_x3_dump_plane(self.ctx.handle, int(which), int(rows), self.n_vis, self.n_hid, vp, int(mode),
+                                               ws.data_ptr(), ws.numel(), out.ptr(), out.ld, self._stream()))
+        return out
+
     def philox_uniform(self, rows, cols, seed, stream_id, step, row0=0):
         with torch.cuda.device(self.device):
             out = DeviceMatrix.zeros(rows, cols, self.device)

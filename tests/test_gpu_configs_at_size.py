@@ -105,6 +105,15 @@ def stagewise_cd_check(e, compute, W, b_h, b_v, v, vd, rows, seed, step, k=1, ro
     dW, dbh, dbv = _split(delta, nv, nh)
     if cd is not None:
         assert np.array_equal(cd.to_numpy(), v_np), "the persistent chain must hold the step's v_neg"
+    if compute == "x3" and k == 1 and chain0 is None:
+        # the planes the FUSED step itself kept -- 0/1 states as k-permuted bytes (row-major) and fp8 / bf16 (transposed), h_neg
+        # as three negated bf16 pieces -- decoded by the library's dump hook: bit for bit the states the half-step hooks
+        # returned for the same counters, which the oracle has just been held to
+        from keras_unsupervised_amd import _lib
+        for which, want in ((_lib.PLANE_H_POS, h_pos), (_lib.PLANE_H_POS_T, h_pos), (_lib.PLANE_V_NEG, v_np),
+                            (_lib.PLANE_V_NEG_T, v_np), (_lib.PLANE_H_NEG_T, h_neg)):
+            got = e.dump_plane(which, vd, rows).to_numpy()
+            assert np.array_equal(got, want), "plane %d of the fused step differs from the hooks' state" % which
     pos = q(vb).astype(np.float64).T @ h_pos.astype(np.float64)                                    # rbm.py:125-126
     neg = v_np.astype(np.float64).T @ q(h_neg).astype(np.float64)
     assert np.max(np.abs(dW - (pos - neg)) / (pos + neg + 1.0)) <= (1e-5 if compute == "bf16" else STAT_TOL)
