@@ -7,6 +7,15 @@ import json
 import re
 import sys
 
+
+def norm(name):
+    """k_gemm_pb<BM, BN, WM, WN, BK, PB, EPI, NOISE, AB[, RP]>: the labels below were written before the RP argument existed."""
+    m = re.match(r"(k_gemm_pb<)([^>]*)(>)", name)
+    if not m:
+        return name
+    args = [a.strip() for a in m.group(2).split(",")]
+    return m.group(1) + ", ".join(args[:9]) + m.group(3) if len(args) == 10 and args[9] == "false" else name
+
 LABEL = {
     ("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true>", 256): "x3_half_step_vh_sample",
     ("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true>", 224): "x3_half_step_hv_sample",
@@ -20,6 +29,7 @@ for path in sys.argv[2:]:
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void kurbm::", "").replace("kurbm::", "")
+        name = norm(name)
         wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
         lab = LABEL.get((name, wgs))
         if lab:

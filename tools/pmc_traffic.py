@@ -8,12 +8,22 @@ import re
 import sys
 
 
+def norm(name):
+    """k_gemm_pb<BM, BN, WM, WN, BK, PB, EPI, NOISE, AB[, RP]>: the labels below were written before the RP argument existed."""
+    m = re.match(r"(k_gemm_pb<)([^>]*)(>)", name)
+    if not m:
+        return name
+    args = [a.strip() for a in m.group(2).split(",")]
+    return m.group(1) + ", ".join(args[:9]) + m.group(3) if len(args) == 10 and args[9] == "false" else name
+
+
 def load(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
         name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void kurbm::", "").replace("kurbm::", "")
+        name = norm(name)
         wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
         acc[(name, wgs)].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
