@@ -5,12 +5,11 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from keras_unsupervised_amd.ebm import MODE_VISIBLE_BERNOULLI, RBM  # noqa: E402
-from keras_unsupervised_amd.ebm.engine import CHAIN_W, DeviceMatrix  # noqa: E402
+from keras_unsupervised_amd.ebm.engine import DeviceMatrix  # noqa: E402
 from keras_unsupervised_amd.ebm.rbm import _ScoreRing  # noqa: E402
 
 B, NV, NH = 4096, 784, 1024
