@@ -32,6 +32,8 @@ for path in sys.argv[2:]:
         name = norm(name)
         wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
         lab = LABEL.get((name, wgs))
+        if lab is None and "k_reduce_apply_split" in name:
+            lab = "x3_reduce_apply"            # (the slab reduce + weight-piece mirror launch: no MFMA, HBM / latency bound)
         if lab:
             acc[(lab, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (lab, c), v in acc.items():
