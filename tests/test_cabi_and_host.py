@@ -148,3 +148,18 @@ def test_graft_entry_build_check_matches_the_abi():
     import __graft_entry__ as g
     src = inspect.getsource(g.build)
     assert "_lib.ABI_VERSION" in src
+
+
+def test_score_ring_prints_in_order_one_step_late():
+    """fit(verbose=1) hands a step's score line to stdout when the NEXT step has been queued (never out of order, at most one
+    step late, everything flushed at an epoch's end): the host-side ring on CPU tensors (no events, no pinned memory)."""
+    from keras_unsupervised_amd.ebm.rbm import _ScoreRing
+    seen = []
+    ring = _ScoreRing(torch.device("cpu"), lambda score, label: seen.append((label, score)), depth=4)
+    for i in range(10):
+        ring.push(torch.tensor([float(i) * 0.5, -1.0, -1.0, -1.0]), (i + 1, 10))
+        assert [l for l, _ in seen] == [(j + 1, 10) for j in range(i)]          # step i's line waits for step i + 1
+    ring.flush()
+    assert seen == [((j + 1, 10), j * 0.5) for j in range(10)]
+    ring.flush()                                                                  # idempotent
+    assert len(seen) == 10

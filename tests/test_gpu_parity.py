@@ -491,6 +491,18 @@ def test_checkpoint_round_trip(gpu_device, tmp_path):
         assert np.array_equal(pa.rbm_weight, pb.rbm_weight)
         fresh = RBM(hps, nh, mode=MODE_VISIBLE_BERNOULLI, seed=3, persistent=True, compute_dtype=compute, weights=pb.get_weights())
         assert fresh._v_chain is None
+        # a chain whose row count is not the batch size is refused -- by fit() (every step reads and rewrites batch_size rows of it
+        # in place) and by load_rbm (a checkpoint edited, or saved under another batch size) -- instead of being read past its end
+        pb.hps = dict(hps, batch_size=32)
+        with pytest.raises(ValueError, match="persistent chain has shape"):
+            pb.fit(V, verbose=0)
+        pb.hps = hps
+        import json as _json
+        meta = _json.load(open(str(tmp_path / "pcd.json")))
+        meta["config"]["hps"]["batch_size"] = 32
+        _json.dump(meta, open(str(tmp_path / "pcd.json"), "w"))
+        with pytest.raises(ValueError, match="checkpoint chain has shape"):
+            load_rbm(str(tmp_path / "pcd"))
     d = DBN()
     d.add_stack(a)
     d.add_stack(RBM(hps, 8, name="top", mode=MODE_VISIBLE_BERNOULLI, seed=4, weights=synthetic_params(nh, 8, 72)))
