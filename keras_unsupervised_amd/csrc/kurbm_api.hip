@@ -621,6 +621,7 @@ struct WorkspaceB {
     uint16_t *vb, *vbT, *hb, *hbT, *v2b, *v2bT, *h2b, *hnT, *cb;
     float *part_h, *part_v, *slab, *tmp32;
     unsigned* sync;     // SYNC_WORDS arrival counters of the fused slab reduction (one per output tile of the statistics)
+    float* rowpart;     // kurbm_score_x3's row partials
     int Kv, Kh, Kb, Lv, Lh, Lb, ldh32, ldv32, max_row_tiles;   // K*: k extents; L*: leading dimensions of the bf16 planes
     size_t planeV, planeVT, planeHT;   // distance between the pieces of v_pos (both images) and of h_neg^T
     size_t slab_stride, bytes;
@@ -701,6 +702,8 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     w.slab = take32(w.slab_stride * pl.nsplit_bound);
     w.tmp32 = take32((size_t)rows * (w.ldh32 > w.ldv32 ? w.ldh32 : w.ldv32));       // fp32 plane for the test hook
     w.sync = reinterpret_cast<unsigned*>(take32(SYNC_WORDS));
+    // the score of fit(verbose = 1): softplus row partials of F(v) and F(v') per 64-column tile, |F - F'| per row
+    w.rowpart = take32((size_t)(2 * ceil_div(n_hid, 64) + 1) * round_up(rows, 4));
     w.bytes = off;
     return w;
 }
@@ -1191,10 +1194,9 @@ int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t m
     const bool f8pos = v_binary && ctx->knob[KN_X3_F8POS] != 0;      // (only so that a conversion here writes what a step would)
     const int vn_pieces = gauss ? 3 : 1;
     const uint32_t base = o->chain * 64u;
-    // row partials of the two free energies live in the (unused here) slab area; |F - F'| per row behind them
-    const int ncol = ceil_div(p->n_hid, 128), ncol_max = ceil_div(p->n_hid, 64), ld_rp = round_up(rows, 4);   // (tiles of 128 / of 64 columns)
-    if ((size_t)(2 * ncol_max + 1) * ld_rp > w.slab_stride) return fail(KURBM_ERR_WORKSPACE, "workspace too small for the score's row partials");
-    float* rp0 = w.slab; float* rp1 = w.slab + (size_t)ncol_max * ld_rp; float* absdiff = rp1 + (size_t)ncol_max * ld_rp;
+    // row partials of the two free energies (one row per 64- or 128-column tile), then |F - F'| per row
+    const int ncol = ceil_div(p->n_hid, 128), ncol_max = ceil_div(p->n_hid, 64), ld_rp = round_up(rows, 4);
+    float* rp0 = w.rowpart; float* rp1 = rp0 + (size_t)ncol_max * ld_rp; float* absdiff = rp1 + (size_t)ncol_max * ld_rp;
     if (!aligned16(p->b_v)) return fail(KURBM_ERR_ARG, "b_v must be 16-byte aligned for the score");
     if (o->v_planes) {
         const VPlanes vp = carve_vplanes(ctx, o->v_planes, rows, p->n_vis, v_pieces);

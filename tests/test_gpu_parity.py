@@ -1344,7 +1344,7 @@ def test_bf16_dp_step_one_call(gpu_device, one_rank_comm, cfg):
 
 
 @pytest.mark.parametrize("cfg", [dict(B=4096, nv=784, nh=1024), dict(B=4096, nv=784, nh=1024, real=True), dict(B=1024, nv=300, nh=200, gauss=True),
-                                 dict(B=1100, nv=260, nh=136), dict(B=2048, nv=784, nh=256, planes=True)])
+                                 dict(B=1100, nv=260, nh=136), dict(B=2048, nv=784, nh=256, planes=True), dict(B=4096, nv=20, nh=16)])
 def test_score_one_call_vs_oracle(gpu_device, cfg):
     """kurbm_score_x3 -- F(v), a fresh one-step reconstruction v', F(v'), mean |F - F'| into a device float, one library call,
     no host synchronisation (rbm.py:225-233; what fit(verbose=1) prints every step) -- against the oracle's step_score with
