@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
 // pass over W instead of three).
 template <int TR>
 __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int tiles_x, int tiles, int nbias) {
+    warm_kernel_arguments<sizeof(ReduceArgs) + 16>();   // (kurbm_device.h: one wait for the argument segment, not one per use)
     __shared__ __attribute__((aligned(16))) float tile[TR][CVT + 1];
     const int t = threadIdx.x;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));

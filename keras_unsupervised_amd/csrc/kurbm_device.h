@@ -7,6 +7,34 @@ namespace kurbm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The kernel-argument segment is cold in the scalar cache at every launch, and hipcc fetches the arguments of a large struct as
+// they are needed: k_gemm_pb's entry waited for SEVEN scalar loads one after the other, ~7 000 cycles (3.3 us) between a wave's
+// first instruction and its first request for data (s_memtime stamps).  Touch every 64-byte line
+// of the segment at once, wait once: the argument loads behind this hit in the scalar cache.
+// (Inline asm: as plain loads hipcc folds them into its own argument loads and waits three times.  Every destination register
+//  stays live until the one wait, so nothing else is allocated to a register a load is still in flight to.)
+typedef const __attribute__((address_space(4))) void* kernarg_ptr_t;
+template <int OFF, int END>
+struct KernargWarm {
+    static __device__ __forceinline__ void go(kernarg_ptr_t ka) {
+        uint32_t d;
+        asm volatile("s_load_dword %0, %1, %2" : "=s"(d) : "s"(ka), "i"(OFF));
+        KernargWarm<OFF + 64, END>::go(ka);
+        asm volatile("" ::"s"(d));
+    }
+};
+template <int END>
+struct KernargWarm<END, END> {
+    static __device__ __forceinline__ void go(kernarg_ptr_t) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+};
+#ifndef KURBM_WARM_ARGS
+#define KURBM_WARM_ARGS 1   // (0: A/B builds)
+#endif
+template <int NBYTES>
+__device__ __forceinline__ void warm_kernel_arguments() {
+    if (KURBM_WARM_ARGS) KernargWarm<0, (NBYTES + 63) / 64 * 64>::go((kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
 // ------------------------------------------------------------------------------------
 // Philox4x32-10 (Random123 constants) -- same contract as oracle/philox.py
 // ------------------------------------------------------------------------------------

@@ -249,6 +249,11 @@ struct GemmArgsB {
     // (8 / (xcd_r xcd_c)) x xcd_r x xcd_c grid over (k slices, row tiles, column tiles); each takes one block of it, so the A
     // rows and B rows it pulls through its own L2 are a fraction of the matrix instead of all of one operand
     int xcd_r, xcd_c;
+    // (launcher) the block mapping's divisions as shifts and multiply-high (divisors < 2^16, dividends < 2^16: exact): a wave's
+    // way to its first request for data is ~600 instructions of set-up, and eight integer divisions were a third of them
+    int map_lrc, map_lxc;               // log2 (xcd_r xcd_c), log2 xcd_c
+    int map_rl, map_cl, map_zl;         // row tiles / column tiles / k slices per XCD block
+    uint32_t map_inv_a, map_inv_b;      // ceil(2^32 / d): d = rl cl, then rl (m fastest) or cl | linear order: d = grid_m grid_n, then grid_m or grid_n
     int any_order;        // caller: TIMING ONLY -- launch without the AQL barrier bit (ctx knob KURBM_ANYORDER); results race
     int xcd2d;            // caller: 1 = let the launcher pick such blocks (ctx knob KURBM_X3_XCD2D), 0 = the linear order
     // softplus epilogue (k_gemm_pb, free energy): rowpart[bn][row] = sum over the tile's columns of softplus(x + bias)

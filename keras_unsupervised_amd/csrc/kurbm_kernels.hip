@@ -193,6 +193,7 @@ __device__ __forceinline__ void fetch_frags(const float* __restrict__ s, int xw,
 // ------------------------------------------------------------------------------------
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KM, bool B_KM, int EPI, int NOISE>
 __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
+    warm_kernel_arguments<sizeof(GemmArgs)>();   // (kurbm_device.h: one wait for the argument segment, not one per use)
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;
@@ -597,6 +598,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
 // (kurbm_kernels.h: bias_colsum_wave); the nblk_w blocks after them sum the split-K slabs of dW (4 columns per thread) and
 // either add lr * dW into W or store dW densely.
 __global__ __launch_bounds__(256) void k_reduce_apply(ReduceArgs a, int nbias, int nbias8) {
+    warm_kernel_arguments<sizeof(ReduceArgs) + 8>();   // (kurbm_device.h: one wait for the argument segment, not one per use)
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < nbias8) {
         if ((int)blockIdx.x < nbias) bias_colsum_wave(a, blockIdx.x * 4 + (tid >> 6), tid & 63);

@@ -61,9 +61,28 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define KURBM_STAMP(var) do { } while (0)
 #endif
 
+#ifndef KURBM_DEEP
+#define KURBM_DEEP 1      // 0: the three-stage schedule of round 3's first half for one-piece byte tiles (A/B builds)
+#endif
+#ifndef KURBM_PRIO_MFMA
+#define KURBM_PRIO_MFMA 2     // s_setprio of the MFMA waves / of the loader waves (A/B builds)
+#endif
+#ifndef KURBM_PRIO_LOADER
+#define KURBM_PRIO_LOADER 0
+#endif
+#ifndef KURBM_PRIO_ENTRY
+#define KURBM_PRIO_ENTRY 3    // the loader waves' priority from the kernel's first instruction to their first barrier (0: A/B builds)
+#endif
+#ifndef KURBM_DEEP_FENCE
+#define KURBM_DEEP_FENCE 1   // the deep schedule's barrier: 1 = __syncthreads (every fragment read has RETURNED), 0 = bare s_barrier
+#endif
+
 // Fused reduction of the statistics GEMM: the rows [lo, hi) of its tile (tile-relative, multiples of 4) that k-slice z reduces
 // -- an even share of the tile's rows that lie inside the matrix, so the last row tile of 784 = 3 x 256 + 16 visible units
 // gives each of its slices 4 rows, not one of them 16.
+// x / d through the launcher's ceil(2^32 / d) (x, d < 2^16: exact; inv == 0 stands for d = 1)
+__device__ __forceinline__ int div_magic(int x, uint32_t inv) { return inv ? (int)__umulhi((uint32_t)x, inv) : x; }
+
 struct FuseRows { int lo, hi; };
 __device__ __forceinline__ FuseRows fuse_rows(const GemmArgsB& g, int m0, int z) {
     int valid = g.M - m0;
@@ -114,9 +133,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     constexpr int TM = WM / 16, TN = WN / 16;
     static_assert(!AB || EPI == EPI_HALFSTEP || EPI == EPI_SOFTPLUS, "byte A tiles: half steps and the free-energy GEMM");
     constexpr int A_BYTES = BM * ROWB, B1_BYTES = BN * ROWB, B_BYTES = PB * B1_BYTES;   // (AB: A_BYTES is a BLOCK, 128 k deep)
-    // LDS: two stages [A tile | B pieces]; AB: two A blocks, then two stages of B pieces
+    // DEEP: one-piece tiles of bytes (the rounded-bf16 path's half steps on 0/1 states) -- 16 MFMAs per wave and tile, a third
+    // of a DMA round trip -- run a deeper pipeline than the three-piece tiles have room for: FOUR B stages and THREE A blocks,
+    // tiles requested four ahead, fragments read two micro-steps (= one tile) ahead ACROSS the tile's barrier (see `deep_tile`)
+    constexpr bool DEEP = AB && PB == 1 && (KURBM_DEEP != 0);
+    constexpr int NAB = DEEP ? 3 : 2;     // A block buffers (AB)
+    // LDS: two stages [A tile | B pieces]; AB: the A blocks, then the stages of B pieces
     constexpr int STAGE = AB ? B_BYTES : A_BYTES + B_BYTES;
-    constexpr int B_OFF = AB ? 2 * A_BYTES : A_BYTES;
+    constexpr int B_OFF = AB ? NAB * A_BYTES : A_BYTES;
     constexpr int NA = BM * CPR / NTS, NB1 = BN * CPR / NTS;   // 1-KiB pieces per loader wave: A tile, ONE piece of B
     static_assert((BM * CPR) % NTS == 0 && (BN * CPR) % NTS == 0 && NA % 2 == 0, "whole pieces per loader wave");
     constexpr int PROW16 = 2 * BN + 16;   // bf16 patch row (bytes)
@@ -124,10 +148,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     constexpr int PATCH_BYTES = (EPI == EPI_SOFTPLUS) ? WAVES_N * BM * 4 : BM * (EPI == EPI_SLAB ? PROW32 : PROW16);
     // One-piece tiles (the rounded-bf16 path) are 16 MFMAs per wave, shorter than the round trip of a tile's DMA: THREE
     // stages, tiles requested two ahead.  (Three-piece tiles: two stages fill the LDS.)
-    constexpr int NSTG = (PB == 1) ? 3 : 2;
-    // (AB: two A blocks of 128 k beside NSTG stages of B pieces; a one-piece tile of bytes -- the rounded-bf16 path's half steps
-    //  on 0/1 states -- keeps the ring of three B stages, the A blocks requested half a block per tile as with two stages)
-    constexpr int STAGES_BYTES = NSTG * (A_BYTES + B_BYTES);
+    constexpr int NSTG = DEEP ? 4 : (PB == 1) ? 3 : 2;
+    // (AB: NAB A blocks of 128 k beside NSTG stages of B pieces, the A blocks requested half a block per tile)
+    constexpr int STAGES_BYTES = AB ? NAB * A_BYTES + NSTG * B_BYTES : NSTG * (A_BYTES + B_BYTES);
     constexpr int SMEM_BYTES = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
     // the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
     // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
@@ -146,6 +169,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave >= NT / 64;                // wave-uniform role
+    // Every wave runs the same ~600 instructions of set-up (block mapping, operand offsets, descriptors) before the roles part,
+    // three waves to a SIMD; what the launch waits for is the loaders' first requests.  They go first until those are out.
+    if (KURBM_PRIO_ENTRY && loader) __builtin_amdgcn_s_setprio(KURBM_PRIO_ENTRY);
     const int stid = tid & 255;                         // loader thread id
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l15 = lane & 15, slot = lane >> 4;
@@ -167,6 +193,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // the first loader wave's loop, summed over its tiles: issue of a tile's DMA / wait for it to land / wait at the barrier;
     // written where MFMA wave 7 would write (that wave's stamps are dropped)
     unsigned long long tl[4] = {0, 0, 0, 0}, tls[3] = {0, 0, 0};
+    // ... and its way to the first barrier (absolute): setup done / the prologue's requests issued / tile 0 has landed
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0};   // (3..5: arguments warm / block mapped / the role branch reached)
+#define KURBM_PSTAMP(q) KURBM_STAMP(tp[q])
 #define KURBM_LSTAMP(q)                                                   \
     do {                                                                  \
         KURBM_STAMP(tl[q]);                                               \
@@ -177,14 +206,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         if (g.stamps && lane == 0 && wave == NT / 64) {                                           \
             unsigned long long* o = g.stamps + ((size_t)blockIdx.x * (NT / 64) + 7) * 16;         \
             o[0] = 1; o[1] = tls[0]; o[2] = tls[1]; o[3] = tls[2];                                \
+            o[4] = ts[0]; o[5] = tp[0]; o[6] = tp[1]; o[7] = tp[2];                               \
+            o[8] = tp[3]; o[9] = tp[4]; o[10] = tp[5];                                            \
         }                                                                                         \
     } while (0)
 #else
 #define KURBM_STAMP_OUT() do { } while (0)
 #define KURBM_LSTAMP(q) do { } while (0)
+#define KURBM_PSTAMP(q) do { } while (0)
 #define KURBM_LSTAMP_OUT() do { } while (0)
 #endif
 
+    warm_kernel_arguments<sizeof(GemmArgsB)>();
+    KURBM_PSTAMP(3);
     const int nwg = gridDim.x;
     if (EPI == EPI_HALFSTEP && g.zero_words && blockIdx.x == 0)   // the arrival counters of the statistics launch behind this one
         for (int i = tid; i < g.n_zero; i += NT + NTS) g.zero_words[i] = 0u;
@@ -193,25 +227,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     if (g.xcd_r) {
         // workgroup i runs on XCD i % 8: XCD (xz, xr, xc) owns k slices [xz zl, +zl), row tiles [xr rl, +rl), column tiles [xc cl, +cl)
         const int xcd = bid & 7, idx = bid >> 3;
-        const int rc = g.xcd_r * g.xcd_c;
-        const int xz = xcd / rc, xr = (xcd - xz * rc) / g.xcd_c, xc = xcd - xz * rc - xr * g.xcd_c;
-        const int rl = g.grid_m / g.xcd_r, cl = g.grid_n / g.xcd_c, zl = g.nsplit / (8 / rc);
-        const int zi = idx / (rl * cl), t2 = idx - zi * (rl * cl);
-        const int ri = g.m_fastest ? t2 % rl : t2 / cl;
-        const int ci = g.m_fastest ? t2 / rl : t2 - ri * cl;
-        z = xz * zl + zi; bm = xr * rl + ri; bn = xc * cl + ci;
+        const int xz = xcd >> g.map_lrc, xr = (xcd & ((1 << g.map_lrc) - 1)) >> g.map_lxc, xc = xcd & ((1 << g.map_lxc) - 1);
+        const int rl = g.map_rl, cl = g.map_cl;
+        const int zi = div_magic(idx, g.map_inv_a), t2 = idx - zi * (rl * cl);
+        const int q2 = div_magic(t2, g.map_inv_b);          // t2 / rl (m fastest) or t2 / cl
+        const int ri = g.m_fastest ? t2 - q2 * rl : q2;
+        const int ci = g.m_fastest ? q2 : t2 - q2 * cl;
+        z = xz * g.map_zl + zi; bm = xr * rl + ri; bn = xc * cl + ci;
     } else {
         {   // XCD-aware bijective remap (see kurbm_kernels.hip)
             const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
             bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
         }
         const int tiles_mn = g.grid_m * g.grid_n;
-        z = bid / tiles_mn;
+        z = div_magic(bid, g.map_inv_a);
         const int tmn = bid - z * tiles_mn;
-        bm = g.m_fastest ? tmn % g.grid_m : tmn / g.grid_n;
-        bn = g.m_fastest ? tmn / g.grid_m : tmn - bm * g.grid_n;
+        const int q2 = div_magic(tmn, g.map_inv_b);        // tmn / grid_m (m fastest) or tmn / grid_n
+        bm = g.m_fastest ? tmn - q2 * g.grid_m : q2;
+        bn = g.m_fastest ? q2 : tmn - q2 * g.grid_n;
     }
     const int m0 = bm * BM, n0 = bn * BN;
+    KURBM_PSTAMP(4);
 
     const int t_begin = z * g.kt_per_split;
     int t_end = t_begin + g.kt_per_split;
@@ -488,6 +524,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         biasv[ni] = (EPI == EPI_HALFSTEP && c < g.N) ? g.bias[c] : 0.f;
     }
     if (loader) {
+        KURBM_PSTAMP(5);
         // ---- loader waves: a loop of their own; one barrier per tile, like the MFMA waves.  `buffer_load_dwordx4 ... lds`,
         // one 1-KiB piece (8 rows of a tile) per wave instruction, straight into the stage that the barrier before has
         // freed; the wait for a tile's pieces and then the tile's barrier make them visible to the MFMA waves
@@ -538,7 +575,72 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             // raw barriers and explicit waits: `s_waitcnt` with expcnt / lgkmcnt not waited for, vmcnt in bits 3:0 and 15:14
             constexpr int VM0 = 0x0F70;
             auto vm = [](int n) constexpr { return VM0 | (n & 15) | ((n >> 4) << 14); };
-            if constexpr (AB && NSTG == 3) {
+            if constexpr (DEEP) {
+                // Tile t = B tile t in stage t % 4 + its share of the A blocks: block j (tiles 2 j, 2 j + 1) in buffer j % 3, its
+                // first half of rows requested with tile 2 j - 1, the second with tile 2 j -- in FRONT of that tile's B pieces, so
+                // "tile t has landed" (a counted vmcnt: NPT pieces per wave and tile) covers everything tile t reads.
+                // Iteration i runs behind barrier i - 1, where the MFMA waves have READ all of tile i (they read one tile ahead):
+                // tile i + 4 goes into tile i's stage, and block (i + 5) / 2 into the buffer of the block tile i was the last of.
+                // Barrier i promises tile i + 2; tiles i + 3 and i + 4 stay in flight across it.
+                constexpr int NPT = NA / 2 + NB1;
+                static_assert(3 * NPT <= 63, "vmcnt");
+                // ONE segment (launch_pb checks): tile t lies 128 t bytes along k in the B operand, block j 128 j bytes in the A
+                // plane -- running scalars, no tile_of in the loop: the loaders' issue is this loop's critical path
+                TileRef rb = tile_of(t_begin);
+                TileRef ra = rb;
+                ra.neg = false;
+                const uint32_t ob0 = rb.ob, oa0 = 128u * (uint32_t)(t_begin >> 1);
+                const int jb_last = (nt - 1) >> 1;
+                // tile t: half (t odd: first, t even: second) of the rows of block jb = (t + 1) / 2 into A buffer ab = jb % 3,
+                // then the B pieces into stage t % 4
+                auto issue = [&](int t, int jb, int ab) __attribute__((always_inline)) {
+                    // (past the last block: the same count of pieces from the last block -- the waits stay exact)
+                    ra.oa = oa0 + 128u * (uint32_t)(jb < jb_last ? jb : jb_last);
+                    if (t & 1) dma_part(0, ra, 1, ab, 0, NA / 2);
+                    else dma_part(0, ra, 1, ab, NA / 2, NA);
+                    rb.ob = ob0 + 128u * (uint32_t)t;
+                    dma_part(t & 3, rb, 2);
+                };
+                ra.oa = oa0;
+                KURBM_PSTAMP(0);
+                dma_part(0, ra, 3, 0);                                  // block 0 whole + B tile 0
+                const int npro = nt < 4 ? nt : 4;
+                if (npro > 1) issue(1, 1, 1);
+                if (npro > 2) issue(2, 1, 1);
+                if (npro > 3) issue(3, 2, 2);
+                KURBM_PSTAMP(1);
+                // barrier P: tile 0 has landed (the MFMA waves read it all, then meet again); barrier -1: tile 1
+                if (npro == 4) __builtin_amdgcn_s_waitcnt(vm(3 * NPT));
+                else if (npro == 3) __builtin_amdgcn_s_waitcnt(vm(2 * NPT));
+                else if (npro == 2) __builtin_amdgcn_s_waitcnt(vm(NPT));
+                else __builtin_amdgcn_s_waitcnt(VM0);
+                KURBM_PSTAMP(2);
+                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
+                __builtin_amdgcn_s_barrier();
+                if (npro == 4) __builtin_amdgcn_s_waitcnt(vm(2 * NPT));
+                else if (npro == 3) __builtin_amdgcn_s_waitcnt(vm(NPT));
+                else __builtin_amdgcn_s_waitcnt(VM0);
+                __builtin_amdgcn_s_barrier();
+                int jb = 2, ab = 2;                                     // of tile t = 4
+                int i = 0;
+                for (; i + 4 < nt; ++i) {
+                    KURBM_LSTAMP(0);
+                    const int t = i + 4;
+                    issue(t, jb, ab);
+                    if (!(t & 1)) { ++jb; ab = (ab == 2) ? 0 : ab + 1; }
+                    KURBM_LSTAMP(1);
+                    __builtin_amdgcn_s_waitcnt(vm(2 * NPT));
+                    KURBM_LSTAMP(2);
+                    __builtin_amdgcn_s_barrier();
+                    KURBM_LSTAMP(3);
+                }
+                for (; i < nt; ++i) {
+                    if (i + 3 < nt) __builtin_amdgcn_s_waitcnt(vm(NPT));
+                    else __builtin_amdgcn_s_waitcnt(VM0);
+                    __builtin_amdgcn_s_barrier();
+                }
+                KURBM_LSTAMP_OUT();
+            } else if constexpr (AB && NSTG == 3) {
                 // one-piece tiles of bytes: the ring of three B stages (tile i + 2 requested while tile i is multiplied, a counted
                 // vmcnt leaves its pieces in flight across the barrier) and the two A blocks of the byte planes, block (i / 2) + 1
                 // requested half a block per tile -- in FRONT of the tile's B pieces, so that the counted wait covers it
@@ -548,6 +650,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 dma_part(0, ra, 3, 0);
                 if (nt > 1) { dma_part(1, tile_of(t_begin + 1), 2); __builtin_amdgcn_s_waitcnt(vm(NBP)); }
                 else __builtin_amdgcn_s_waitcnt(VM0);
+                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
                 __builtin_amdgcn_s_barrier();
                 int nb = 2;   // stage of tile i + 2
                 for (int i = 0; i < nt; ++i) {
@@ -571,8 +674,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 // i + 1 and HALF of block i / 2 + 1 are requested (its buffer was freed by tile 2 (i / 2) - 1)
                 TileRef ra = tile_of(t_begin);
                 ra.neg = false; ra.oa = 0u;
+                KURBM_PSTAMP(0);
                 dma_part(0, ra, 3, 0);
+                KURBM_PSTAMP(1);
                 __builtin_amdgcn_s_waitcnt(VM0);
+                KURBM_PSTAMP(2);
+                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
                 __builtin_amdgcn_s_barrier();
                 for (int i = 0; i < nt; ++i) {
                     KURBM_LSTAMP(0);
@@ -597,6 +704,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 dma_tile(0, tile_of(t_begin));
                 if (nt > 1) dma_tile(1, tile_of(t_begin + 1));
                 if (nt > 1) __builtin_amdgcn_s_waitcnt(vm(NP)); else __builtin_amdgcn_s_waitcnt(VM0);
+                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
                 __builtin_amdgcn_s_barrier();
                 int nb = 2;   // stage of tile i + 2
                 for (int i = 0; i < nt; ++i) {
@@ -622,6 +730,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             } else {
                 __builtin_amdgcn_s_waitcnt(VM0);
             }
+            __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
             __builtin_amdgcn_s_barrier();
             for (int i = 0; i < nt; ++i) {
                 KURBM_LSTAMP(0);
@@ -676,7 +785,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         const int nbw = bias_waves(g.red);
         for (int gi = (int)blockIdx.x * (NT / 64) + wave; gi < nbw; gi += nwg * (NT / 64)) bias_colsum_wave(g.red, gi, lane);
     }
-    __builtin_amdgcn_s_setprio(2);   // the MFMA waves go first wherever a loader wave competes for issue (the reverse: no difference)
+    __builtin_amdgcn_s_setprio(KURBM_PRIO_MFMA);   // the MFMA waves go first wherever a loader wave competes for issue (the reverse: no difference)
     if (nt > 0) {
         __syncthreads();
         frag_a(0, 0, fa[0]);
@@ -685,7 +794,82 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         KURBM_STAMP(ts[1]);
         // unrolled by two: the LDS buffers alternate statically
         int i = 0;
-        if constexpr (NSTG == 3 && AB) {
+        if constexpr (DEEP) {
+            // (the pre-loop reads above took tile 0's k-step 0; behind barrier P the rest of tile 0, then barrier -1)
+            const uint32_t la = (uint32_t)((wm * WM + l15) * ROWB + 16 * (slot ^ swz));            // + block; ^ 64: second tile of the block
+            const uint32_t lb = (uint32_t)(B_OFF + (wn * WN + l15) * ROWB + 16 * (slot ^ swz));    // + stage; ^ 64: k-step 1
+            auto rd_a = [&](uint32_t blk_off, int half, afrag (&f)[TM]) __attribute__((always_inline)) {
+                const unsigned char* c = smem + ((la ^ (64u * (uint32_t)half)) + blk_off);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
+            };
+            auto rd_b = [&](uint32_t stg_off, int ks, u32x4 (&f)[TN]) __attribute__((always_inline)) {
+                const unsigned char* c = smem + ((lb ^ (64u * (uint32_t)ks)) + stg_off);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) f[ni] = *reinterpret_cast<const u32x4*>(c + ni * 16 * ROWB);
+            };
+            auto expand_from = [&](const afrag (&f)[TM], int ks) __attribute__((always_inline)) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const uint32_t lo = ks ? f[mi].z : f[mi].x, hi = ks ? f[mi].w : f[mi].y;
+                    fx[mi] = u32x4{__builtin_amdgcn_perm(0u, lo, 0x010C000Cu), __builtin_amdgcn_perm(0u, lo, 0x030C020Cu),
+                                   __builtin_amdgcn_perm(0u, hi, 0x010C000Cu), __builtin_amdgcn_perm(0u, hi, 0x030C020Cu)};
+                }
+            };
+            auto deep_barrier = [&]() __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+#if KURBM_DEEP_FENCE
+                __syncthreads();
+#else
+                __builtin_amdgcn_s_barrier();
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            u32x4 fb4[4][TN];                      // B fragments of micro-steps m, m + 1, m + 2 (m = 2 i + k-step), index m % 4
+            uint32_t sbn = B_BYTES;                // stage of tile i + 1
+            uint32_t oab = 0u, oan = A_BYTES;      // A block of the tile pair in work, of the next pair
+            // Tile i of parity P, entered with fx = A(i, k-step 0) expanded, fa[P] = A(i) raw, fb4[2 P], fb4[2 P + 1] = B(i):
+            // every read is for tile i + 1, two micro-steps ahead of the MFMAs that use it -- no read waits behind the barrier.
+            // (The permutes stay BEHIND a k-step's MFMAs: two MFMAs / four permutes alternating measured 3 % slower.)
+            auto deep_tile = [&](auto par_tag) __attribute__((always_inline)) {
+                constexpr int P = decltype(par_tag)::value;
+#ifdef KURBM_STAMPS
+                unsigned long long tq0, tq1, tq2;   // tk[0]: the tiles up to their barrier, tk[1]: at the barrier (tu[] belongs to the epilogue)
+                KURBM_STAMP(tq0);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if (P == 0) rd_a(oab, 1, fa[1]); else rd_a(oan, 0, fa[0]);
+                rd_b(sbn, 0, fb4[(2 * P + 2) & 3]);
+                mfmas(fa[0], fb4[2 * P]);
+                __builtin_amdgcn_sched_barrier(0);
+                expand_from(fa[P], 1);
+                __builtin_amdgcn_sched_barrier(0);
+                rd_b(sbn, 1, fb4[(2 * P + 3) & 3]);
+                mfmas(fa[0], fb4[2 * P + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                expand_from(fa[P ^ 1], 0);
+#ifdef KURBM_STAMPS
+                KURBM_STAMP(tq1);
+#endif
+                deep_barrier();
+#ifdef KURBM_STAMPS
+                KURBM_STAMP(tq2);
+                tk[0] += tq1 - tq0; tk[1] += tq2 - tq1;
+#endif
+                sbn = (sbn + B_BYTES == NSTG * B_BYTES) ? 0u : sbn + B_BYTES;
+                if (P == 1) { oab = oan; oan = (oan + A_BYTES == NAB * A_BYTES) ? 0u : oan + A_BYTES; }
+            };
+            // tile 0: fa[0] was read above (k-step 0 = half 0 of block 0: the same 16 bytes hold both k-steps), fb[0] = B(0, 0)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) fb4[0][ni] = fb[0][ni];
+            rd_b(0u, 1, fb4[1]);
+            deep_barrier();
+            for (; i + 1 < nt; i += 2) {
+                deep_tile(std::integral_constant<int, 0>{});
+                deep_tile(std::integral_constant<int, 1>{});
+            }
+            if (i < nt) deep_tile(std::integral_constant<int, 0>{});
+        } else if constexpr (NSTG == 3 && AB) {
             // three B stages, two halves of an A block: the (stage, half) pattern repeats every six tiles
             for (; i + 5 < nt; i += 6) {
                 tile_any(0, 0, tile_of(t_begin + i));
@@ -1211,6 +1395,7 @@ static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
             KURBM_LAUNCH((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             return hipGetLastError();
         } else if constexpr (E == EPI_HALFSTEP) {
+            if (PBN == 1 && (g.nseg != 1 || g.nsplit != 1)) return hipErrorInvalidValue;   // (the deep loader loop walks ONE segment)
             if (g.cfg == 2) KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             else if (g.cfg == 0) KURBM_LAUNCH((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             else return hipErrorInvalidValue;
@@ -1266,6 +1451,21 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
                     const long long cost = (long long)(g.nsplit / xz) * ((long long)(g.grid_m / xr) * bmr * wa + (long long)(g.grid_n / xc) * bnr * wb);
                     if (best < 0 || cost < best) { best = cost; g.xcd_r = xr; g.xcd_c = xc; }
                 }
+        }
+    }
+    {   // the block mapping's divisors as multiply-high constants (exact for dividends and divisors below 2^16)
+        if (nblk <= 0 || nblk >= 65536) return hipErrorInvalidValue;
+        auto inv = [](int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); };   // d = 1: 2^32 wraps to 0, which div_magic reads as "divisor 1"
+        if (g.xcd_r) {
+            const int rc = g.xcd_r * g.xcd_c;
+            g.map_lrc = __builtin_ctz(rc); g.map_lxc = __builtin_ctz(g.xcd_c);
+            g.map_rl = g.grid_m / g.xcd_r; g.map_cl = g.grid_n / g.xcd_c; g.map_zl = g.nsplit / (8 / rc);
+            g.map_inv_a = inv(g.map_rl * g.map_cl);
+            g.map_inv_b = inv(g.m_fastest ? g.map_rl : g.map_cl);
+        } else {
+            g.map_lrc = g.map_lxc = 0; g.map_rl = g.map_cl = g.map_zl = 0;
+            g.map_inv_a = inv(g.grid_m * g.grid_n);
+            g.map_inv_b = inv(g.m_fastest ? g.grid_m : g.grid_n);
         }
     }
     // cfg 2: 256 x 64 tiles for the half steps (A tile 32 KB + three 8-KB pieces of B = 56 KB per k-tile instead of 64 KB

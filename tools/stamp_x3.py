@@ -59,6 +59,16 @@ for n, name in enumerate(("vh sample", "hv sample", "vh prob", "statistics")):
     if len(lw):   # the first loader wave's loop: cycles summed over its tiles
         print("           loader wave: issue %6.0f  wait for landing %6.0f  wait at the barrier %6.0f"
               % tuple(np.median(lw[:, q]) for q in (1, 2, 3)))
+        w0 = s[n, :, 0]
+        w0 = w0[w0[:, 0] > 0]
+        t0 = w0[:, 0].min()
+        if lw[:, 5].max() > 0:
+            print("           since the launch's first wave: MFMA wave 0 starts %5.0f, first reads done %5.0f | loader wave starts %5.0f, "
+                  "set up %5.0f, first requests issued %5.0f, tile 0 landed %5.0f"
+                  % ((np.median(w0[:, 0]) - t0, np.median(w0[:, 1]) - t0) + tuple(np.median(lw[:, q]) - t0 for q in (4, 5, 6, 7))))
+            d = lw[:, 4:11] - lw[:, 4:5]
+            print("           loader wave, cycles since its own start: arguments warm %5.0f, block mapped %5.0f, role branch %5.0f, set up %5.0f, "
+                  "first requests issued %5.0f, tile 0 landed %5.0f" % tuple(np.median(d[:, q]) for q in (4, 5, 6, 1, 2, 3)))
     if n == 0:
         for wv in (1, 4, 5):
             report("  wave %d" % wv, s[n, :, wv])
