@@ -185,35 +185,56 @@ struct FinishArgs {
 // seg_codes packs one 5-bit code per segment: bits 0-1 ia, bits 2-3 npb, bit 4 set.
 constexpr int MAX_SEG = 12;
 struct GemmArgsB {
+    // ---- the WALK: everything a wave reads between its first instruction and its first request for data comes first and
+    // together (three 64-byte lines of the argument segment): the scalar loads of the kernel's entry are then a few wide
+    // ones, not a chain of narrow ones -- each costs its latency even when it hits the scalar cache (DESIGN.md section 4,
+    // round 3, "the entry of a launch")
     const uint16_t* A0;
-    const uint16_t* B0;
     const uint16_t* A1;
-    const uint16_t* B1;
-    size_t a_plane0, b_plane0, a_plane1, b_plane1;
+    // filled by launch_gemm_pb: one buffer descriptor per operand (base = the lower of the two sets'
+    // pointers) and each set's byte offset from it, so that a tile is a scalar offset, never a pointer
+    const uint16_t* baseB;
+    size_t a_plane0, a_plane1, b_plane0, b_plane1;
     unsigned long long seg_codes;
+    // EPI_HALFSTEP: workgroup 0 stores n_zero zeros here (the arrival counters of the statistics GEMM that follows)
+    unsigned* zero_words;
     uint32_t inv_nkt;     // floor(2^32 / nkt) + 1: segment of k-tile t = umulhi(t, inv_nkt)
+    uint32_t inv_nseg;
+    uint32_t offB0, offB1;
+    // (launcher) the block mapping's divisions as shifts and multiply-high (divisors < 2^16, dividends < 2^16: exact): a wave's
+    // way to its first request for data was ~600 instructions of set-up, and eight integer divisions were a third of them
+    uint32_t map_inv_a, map_inv_b;      // ceil(2^32 / d): d = rl cl, then rl (m fastest) or cl | linear order: d = grid_m grid_n, then grid_m or grid_n
+    int map_lrc, map_lxc;               // log2 (xcd_r xcd_c), log2 xcd_c
+    int map_rl, map_cl, map_zl;         // row tiles / column tiles / k slices per XCD block
+    // k_gemm_pb: XCD-aware 2-D blocks (set by the launcher; xcd_r == 0: the linear order).  The 8 XCDs form a
+    // (8 / (xcd_r xcd_c)) x xcd_r x xcd_c grid over (k slices, row tiles, column tiles); each takes one block of it, so the A
+    // rows and B rows it pulls through its own L2 are a fraction of the matrix instead of all of one operand
+    int xcd_r, xcd_c;
+    int n_zero;
     // k_gemm_pb (kurbm_x3.hip) reads the code as: bits 0-1 ia, bits 2-3 npb = number of B pieces
     // (0 .. npb-1) multiplied with that A tile, bit 4 set; and may walk the segments FASTEST
     // (t = k-tile * nseg + segment), so that every split-K slice gets the same mix of light and heavy tiles
     int seg_fastest;
-    uint32_t inv_nseg;
     // statistics GEMM with 0/1 data: segment 0 (v_pos^T h_pos, both operands 0/1) reads fp8 planes and runs on
     // v_mfma_scale_f32_16x16x128_f8f6f4 -- a k-tile of the same 128 BYTES per row is 128 deep, at twice the bf16 rate and
     // half the bytes per k.  The walk is then in UNITS of 128 k: one fp8 tile, then two 64-deep bf16 tiles of every other
     // segment (2 nseg - 1 tiles per unit; inv_nseg inverts that count)
     int f8pos;
-    int side;             // k_gemm_pb: some test plane (prob_f32 / out_u) is requested
-    int pb_max;           // k_gemm_pb: most B pieces any segment multiplies (3: x3; 1: the rounded-bf16 path)
-    // filled by launch_gemm_pb: one buffer descriptor per operand (base = the lower of the two sets'
-    // pointers) and each set's byte offset from it, so that a tile is a scalar offset, never a pointer
-    const uint16_t* baseA;
-    const uint16_t* baseB;
-    uint32_t offA0, offA1, offB0, offB1;
     int lda, ldb;         // elements, multiples of 8
     int M, N, K;          // K per segment, multiple of 64 (the operands are zero-padded to 128)
     int nseg, nkt, kt_total, kt_per_split, nsplit;
     int grid_m, grid_n;
     int m_fastest;
+    int a_bytes;          // the A operand is such a byte plane (lda bytes between its rows; one segment): k_gemm_pb<..., AB>
+    int walk3;            // (launcher) f8pos with ONE other segment of three pieces: the tiles go fp8, 3-piece, 3-piece, ... in whole
+                          // units per k slice, and both loops of the statistics kernel step through that pattern instead of decoding a tile list
+    // ---- the rest
+    const uint16_t* B0;
+    const uint16_t* B1;
+    const uint16_t* baseA;
+    uint32_t offA0, offA1;
+    int side;             // k_gemm_pb: some test plane (prob_f32 / out_u) is requested
+    int pb_max;           // k_gemm_pb: most B pieces any segment multiplies (3: x3; 1: the rounded-bf16 path)
     int cfg;              // 0: 128 x 128 tile; 2: 256 x 64 (half steps)
     // half-step epilogue
     const float* bias;
@@ -223,7 +244,6 @@ struct GemmArgsB {
     int ldo;
     int out_pieces;       // k_gemm_pb: 1 = the plane is 0/1 (one exact piece); 3 = real-valued, hi / mid / lo, out_plane apart
     int out_bytes;        // the row-major plane of a 0/1 sample leaves as BYTES (0x40 = one), ldo bytes between its rows
-    int a_bytes;          // the A operand is such a byte plane (lda bytes between its rows; one segment): k_gemm_pb<..., AB>
     size_t out_plane;
     int ldo_cols;         // columns the row planes cover: ldo when `out` is set (pads are zeroed), else N
     uint16_t* outT;       // bf16 [N][ldoT]  the same plane transposed; nullable
@@ -245,15 +265,6 @@ struct GemmArgsB {
     float* slab;
     size_t slab_stride;
     int ld_slab;
-    // k_gemm_pb: XCD-aware 2-D blocks (set by the launcher; xcd_r == 0: the linear order).  The 8 XCDs form a
-    // (8 / (xcd_r xcd_c)) x xcd_r x xcd_c grid over (k slices, row tiles, column tiles); each takes one block of it, so the A
-    // rows and B rows it pulls through its own L2 are a fraction of the matrix instead of all of one operand
-    int xcd_r, xcd_c;
-    // (launcher) the block mapping's divisions as shifts and multiply-high (divisors < 2^16, dividends < 2^16: exact): a wave's
-    // way to its first request for data is ~600 instructions of set-up, and eight integer divisions were a third of them
-    int map_lrc, map_lxc;               // log2 (xcd_r xcd_c), log2 xcd_c
-    int map_rl, map_cl, map_zl;         // row tiles / column tiles / k slices per XCD block
-    uint32_t map_inv_a, map_inv_b;      // ceil(2^32 / d): d = rl cl, then rl (m fastest) or cl | linear order: d = grid_m grid_n, then grid_m or grid_n
     int any_order;        // caller: TIMING ONLY -- launch without the AQL barrier bit (ctx knob KURBM_ANYORDER); results race
     int xcd2d;            // caller: 1 = let the launcher pick such blocks (ctx knob KURBM_X3_XCD2D), 0 = the linear order
     // softplus epilogue (k_gemm_pb, free energy): rowpart[bn][row] = sum over the tile's columns of softplus(x + bias)
@@ -268,9 +279,6 @@ struct GemmArgsB {
     unsigned* sync;
     unsigned* status;
     ReduceArgs red;
-    // EPI_HALFSTEP: workgroup 0 stores n_zero zeros here (the arrival counters of the statistics GEMM that follows)
-    unsigned* zero_words;
-    int n_zero;
     // diagnostic build only (KURBM_STAMPS): 8 x u64 per workgroup (k_gemm_pb)
     unsigned long long* stamps;
 };

@@ -61,9 +61,6 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define KURBM_STAMP(var) do { } while (0)
 #endif
 
-#ifndef KURBM_DEEP
-#define KURBM_DEEP 1      // 0: the three-stage schedule of round 3's first half for one-piece byte tiles (A/B builds)
-#endif
 #ifndef KURBM_PRIO_MFMA
 #define KURBM_PRIO_MFMA 2     // s_setprio of the MFMA waves / of the loader waves (A/B builds)
 #endif
@@ -136,7 +133,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // DEEP: one-piece tiles of bytes (the rounded-bf16 path's half steps on 0/1 states) -- 16 MFMAs per wave and tile, a third
     // of a DMA round trip -- run a deeper pipeline than the three-piece tiles have room for: FOUR B stages and THREE A blocks,
     // tiles requested four ahead, fragments read two micro-steps (= one tile) ahead ACROSS the tile's barrier (see `deep_tile`)
-    constexpr bool DEEP = AB && PB == 1 && (KURBM_DEEP != 0);
+    constexpr bool DEEP = AB && PB == 1;
     constexpr int NAB = DEEP ? 3 : 2;     // A block buffers (AB)
     // LDS: two stages [A tile | B pieces]; AB: the A blocks, then the stages of B pieces
     constexpr int STAGE = AB ? B_BYTES : A_BYTES + B_BYTES;
@@ -220,8 +217,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     warm_kernel_arguments<sizeof(GemmArgsB)>();
     KURBM_PSTAMP(3);
     const int nwg = gridDim.x;
-    if (EPI == EPI_HALFSTEP && g.zero_words && blockIdx.x == 0)   // the arrival counters of the statistics launch behind this one
-        for (int i = tid; i < g.n_zero; i += NT + NTS) g.zero_words[i] = 0u;
     int bid = blockIdx.x;
     int z, bm, bn;
     if (g.xcd_r) {
@@ -523,7 +518,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         const int c = n0 + wn * WN + l15 + ni * 16;
         biasv[ni] = (EPI == EPI_HALFSTEP && c < g.N) ? g.bias[c] : 0.f;
     }
-    if (loader) {
+    if (loader) {   // (NOT marked likely: the loaders would reach their first request ~1 000 cycles sooner, but hipcc then treats the
+                    //  MFMA waves' path as cold and their k loop takes 1.5 x the time)
         KURBM_PSTAMP(5);
         // ---- loader waves: a loop of their own; one barrier per tile, like the MFMA waves.  `buffer_load_dwordx4 ... lds`,
         // one 1-KiB piece (8 rows of a tile) per wave instruction, straight into the stage that the barrier before has
@@ -640,39 +636,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     __builtin_amdgcn_s_barrier();
                 }
                 KURBM_LSTAMP_OUT();
-            } else if constexpr (AB && NSTG == 3) {
-                // one-piece tiles of bytes: the ring of three B stages (tile i + 2 requested while tile i is multiplied, a counted
-                // vmcnt leaves its pieces in flight across the barrier) and the two A blocks of the byte planes, block (i / 2) + 1
-                // requested half a block per tile -- in FRONT of the tile's B pieces, so that the counted wait covers it
-                constexpr int NBP = NB1;   // (pieces per loader wave of one B tile)
-                TileRef ra = tile_of(t_begin);
-                ra.neg = false; ra.oa = 0u;
-                dma_part(0, ra, 3, 0);
-                if (nt > 1) { dma_part(1, tile_of(t_begin + 1), 2); __builtin_amdgcn_s_waitcnt(vm(NBP)); }
-                else __builtin_amdgcn_s_waitcnt(VM0);
-                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
-                __builtin_amdgcn_s_barrier();
-                int nb = 2;   // stage of tile i + 2
-                for (int i = 0; i < nt; ++i) {
-                    const int jb = (i >> 1) + 1;
-                    if (2 * jb < nt) {
-                        ra.oa = __builtin_amdgcn_readfirstlane(128u * (uint32_t)((t_begin >> 1) + jb));
-                        if (i & 1) dma_part(0, ra, 1, jb & 1, NA / 2, NA);
-                        else dma_part(0, ra, 1, jb & 1, 0, NA / 2);
-                    }
-                    if (i + 2 < nt) {
-                        dma_part(nb, tile_of(t_begin + i + 2), 2);
-                        __builtin_amdgcn_s_waitcnt(vm(NBP));
-                    } else {
-                        __builtin_amdgcn_s_waitcnt(VM0);
-                    }
-                    nb = nb == 2 ? 0 : nb + 1;
-                    __builtin_amdgcn_s_barrier();
-                }
             } else if constexpr (AB) {
                 // A block j (128 k of bytes) serves tiles 2 j and 2 j + 1; while tile i is multiplied, the B pieces of tile
                 // i + 1 and HALF of block i / 2 + 1 are requested (its buffer was freed by tile 2 (i / 2) - 1)
+                // (ONE segment -- launch_pb checks: B tile t lies 128 t bytes along k; no tile_of in the loop)
                 TileRef ra = tile_of(t_begin);
+                TileRef rb = ra;
+                const uint32_t ob0 = ra.ob;
                 ra.neg = false; ra.oa = 0u;
                 KURBM_PSTAMP(0);
                 dma_part(0, ra, 3, 0);
@@ -683,7 +653,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 __builtin_amdgcn_s_barrier();
                 for (int i = 0; i < nt; ++i) {
                     KURBM_LSTAMP(0);
-                    if (i + 1 < nt) dma_part((i + 1) & 1, tile_of(t_begin + i + 1), 2);
+                    if (i + 1 < nt) { rb.ob = ob0 + 128u * (uint32_t)(i + 1); dma_part((i + 1) & 1, rb, 2); }
                     const int jb = (i >> 1) + 1;
                     if (2 * jb < nt) {
                         ra.oa = __builtin_amdgcn_readfirstlane(128u * (uint32_t)((t_begin >> 1) + jb));
@@ -732,6 +702,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             }
             __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
             __builtin_amdgcn_s_barrier();
+            if (F8 && g.walk3) {
+                // fp8, 3-piece, 3-piece, ...: the fp8 tile of unit u lies 128 u bytes along k in its planes, the two other tiles
+                // 128 (2 u), 128 (2 u + 1) in theirs -- two running tile references, no tile list
+                TileRef rp = tile_of(t_begin), rn = tile_of(t_begin + 1);
+                int kind = 2;                        // of tile i + 1 = 2: the second 3-piece tile of unit 0
+                rn.oa += 128u; rn.ob += 128u;
+                rp.oa += 128u; rp.ob += 128u;        // (the fp8 tile of unit 1)
+                for (int i = 0; i < nt; ++i) {
+                    KURBM_LSTAMP(0);
+                    if (i >= 1 && i + 1 < nt) {
+                        if (kind == 0) { dma_tile((i + 1) & 1, rp); rp.oa += 128u; rp.ob += 128u; }
+                        else { dma_tile((i + 1) & 1, rn); rn.oa += 128u; rn.ob += 128u; }
+                    }
+                    if (i >= 1) kind = (kind == 2) ? 0 : kind + 1;
+                    KURBM_LSTAMP(1);
+                    __builtin_amdgcn_s_waitcnt(VM0);
+                    KURBM_LSTAMP(2);
+                    __builtin_amdgcn_s_barrier();
+                    KURBM_LSTAMP(3);
+                }
+            } else {
             for (int i = 0; i < nt; ++i) {
                 KURBM_LSTAMP(0);
                 if (i >= 1 && i + 1 < nt) dma_tile((i + 1) & 1, tile_of(t_begin + i + 1));
@@ -740,6 +731,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 KURBM_LSTAMP(2);
                 __builtin_amdgcn_s_barrier();
                 KURBM_LSTAMP(3);
+            }
             }
             KURBM_LSTAMP_OUT();
             }
@@ -765,6 +757,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         }
         return;
     }
+    if (EPI == EPI_HALFSTEP && g.zero_words && blockIdx.x == 0)   // the arrival counters of the statistics launch behind this one
+        for (int i = tid; i < g.n_zero; i += NT) g.zero_words[i] = 0u;   // (the MFMA waves: off the loaders' way to their first requests)
     if constexpr (NI_LDS > 0) {
         if (nt > 0) {
 #pragma unroll
@@ -869,24 +863,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 deep_tile(std::integral_constant<int, 1>{});
             }
             if (i < nt) deep_tile(std::integral_constant<int, 0>{});
-        } else if constexpr (NSTG == 3 && AB) {
-            // three B stages, two halves of an A block: the (stage, half) pattern repeats every six tiles
-            for (; i + 5 < nt; i += 6) {
-                tile_any(0, 0, tile_of(t_begin + i));
-                tile_any(1, 1, tile_of(t_begin + i + 1));
-                ablk ^= 1;
-                tile_any(2, 0, tile_of(t_begin + i + 2));
-                tile_any(0, 1, tile_of(t_begin + i + 3));
-                ablk ^= 1;
-                tile_any(1, 0, tile_of(t_begin + i + 4));
-                tile_any(2, 1, tile_of(t_begin + i + 5));
-                ablk ^= 1;
-            }
-            if (i < nt) tile_any(0, 0, tile_of(t_begin + i));
-            if (i + 1 < nt) { tile_any(1, 1, tile_of(t_begin + i + 1)); ablk ^= 1; }
-            if (i + 2 < nt) tile_any(2, 0, tile_of(t_begin + i + 2));
-            if (i + 3 < nt) { tile_any(0, 1, tile_of(t_begin + i + 3)); ablk ^= 1; }
-            if (i + 4 < nt) tile_any(1, 0, tile_of(t_begin + i + 4));
         } else if constexpr (NSTG == 3) {
             for (; i + 2 < nt; i += 3) {
                 tile_any(0, 0, tile_of(t_begin + i));
@@ -896,12 +872,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             if (i < nt) tile_any(0, 0, tile_of(t_begin + i));
             if (i + 1 < nt) tile_any(1, 0, tile_of(t_begin + i + 1));
         } else {
-            for (; i + 1 < nt; i += 2) {
-                tile_any(0, 0, tile_of(t_begin + i));
-                tile_any(1, 1, tile_of(t_begin + i + 1));
-                ablk ^= 1;
+            if constexpr (AB) {
+                // one segment of PB pieces (launch_pb checks): every tile is the same tile -- no tile list, no dispatch
+                for (; i + 1 < nt; i += 2) {
+                    one_tile(0, 0, std::integral_constant<int, PB>{});
+                    one_tile(1, 1, std::integral_constant<int, PB>{});
+                    ablk ^= 1;
+                }
+                if (i < nt) one_tile(0, 0, std::integral_constant<int, PB>{});
+            } else {
+                if (F8 && g.walk3) {
+                    // whole units of fp8, 3-piece, 3-piece; the stages alternate: six tiles per trip
+                    for (; i + 5 < nt; i += 6) {
+                        f8_tile(0);
+                        one_tile(1, 1, std::integral_constant<int, 3>{});
+                        one_tile(0, 0, std::integral_constant<int, 3>{});
+                        f8_tile(1);
+                        one_tile(0, 0, std::integral_constant<int, 3>{});
+                        one_tile(1, 1, std::integral_constant<int, 3>{});
+                    }
+                    if (i < nt) {
+                        f8_tile(0);
+                        one_tile(1, 1, std::integral_constant<int, 3>{});
+                        one_tile(0, 0, std::integral_constant<int, 3>{});
+                    }
+                } else {
+                for (; i + 1 < nt; i += 2) {
+                    tile_any(0, 0, tile_of(t_begin + i));
+                    tile_any(1, 1, tile_of(t_begin + i + 1));
+                    ablk ^= 1;
+                }
+                if (i < nt) tile_any(0, 0, tile_of(t_begin + i));
+                }
             }
-            if (i < nt) tile_any(0, 0, tile_of(t_begin + i));
         }
     }
     __syncthreads();
@@ -1378,6 +1381,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     } while (0)
 template <int PBN, int E, int NZ>
 static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
+    // byte A planes: ONE segment of PBN pieces, one k slice -- those kernels' loops do not walk a tile list
+    if (g.a_bytes && (g.nseg != 1 || g.nsplit != 1 || (int)((g.seg_codes >> 2) & 3u) != PBN)) return hipErrorInvalidValue;
     if constexpr (E == EPI_HALFSTEP && PBN == 3 && (NZ == NOISE_BERNOULLI || NZ == NOISE_NONE)) {
         if (g.rp) {   // the score's half steps: (samples AND) the softplus row sums of their rows
             if (!g.rowpart) return hipErrorInvalidValue;
@@ -1395,7 +1400,6 @@ static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
             KURBM_LAUNCH((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             return hipGetLastError();
         } else if constexpr (E == EPI_HALFSTEP) {
-            if (PBN == 1 && (g.nseg != 1 || g.nsplit != 1)) return hipErrorInvalidValue;   // (the deep loader loop walks ONE segment)
             if (g.cfg == 2) KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             else if (g.cfg == 0) KURBM_LAUNCH((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             else return hipErrorInvalidValue;
@@ -1453,6 +1457,8 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
                 }
         }
     }
+    g.walk3 = (epi == EPI_SLAB && g.pb_max == 3 && g.f8pos && g.nseg == 2 && ((g.seg_codes >> 7) & 3u) == 3u &&
+               g.kt_per_split % 3 == 0 && g.kt_total % 3 == 0) ? 1 : 0;
     {   // the block mapping's divisors as multiply-high constants (exact for dividends and divisors below 2^16)
         if (nblk <= 0 || nblk >= 65536) return hipErrorInvalidValue;
         auto inv = [](int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); };   // d = 1: 2^32 wraps to 0, which div_magic reads as "divisor 1"
