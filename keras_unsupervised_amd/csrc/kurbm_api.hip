@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_COUNT };
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
@@ -40,6 +40,7 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_DP_CHUNKS", 0},        // row ranges of dW in the data-parallel step when the caller passes n_chunks <= 0; 0: by message size
     {"KURBM_ANYORDER", 0},         // TIMING ONLY (results race): bit 0 the half steps, bit 1 the statistics GEMM are launched without
                                    // the AQL barrier bit -- the upper bound of what overlapping dependent launches could gain
+    {"KURBM_X3_STATS_BYTES", 1},   // 0: v_neg^T reaches the statistics GEMM as a bf16 plane (1: as bytes where the positive half is fp8)
 };
 
 struct kurbm_ctx {
@@ -736,6 +737,7 @@ struct HalfOutB {
     int outT_pieces = 1; size_t outT_plane = 0;
     bool outT_neg = false;                                // the transposed plane is stored negated
     bool outT_f8 = false;                                 // the transposed plane of a 0/1 sample as fp8 bytes
+    bool outT_b8 = false;                                 // ... as k-permuted bytes (0x40 = one), at the bf16 plane's row stride
     bool out_bytes = false;                               // the row-major plane of a 0/1 sample as bytes (0x40 = one)
     float* out_f32 = nullptr; float* prob_f32 = nullptr; float* out_u = nullptr; int ldo32 = 0;
     float* colpart = nullptr; int ld_colpart = 0;
@@ -784,7 +786,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.out = o.out; g.ldo = o.ldo; g.ldo_cols = o.out ? o.ldo : g.N;
         g.out_pieces = o.out_pieces; g.out_plane = o.out_plane; g.out_bytes = o.out_bytes ? 1 : 0;
         g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
-        g.outT_neg = o.outT_neg ? 1 : 0; g.outT_f8 = o.outT_f8 ? 1 : 0;
+        g.outT_neg = o.outT_neg ? 1 : 0; g.outT_f8 = o.outT_b8 ? 2 : o.outT_f8 ? 1 : 0;
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
         g.colpart = o.colpart; g.ld_colpart = o.ld_colpart; g.colsign = o.colsign;
         g.zero_words = o.zero_words; g.n_zero = o.n_zero;
@@ -907,6 +909,9 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     // (the rounded-bf16 path too: its 0/1 states are exact as bytes, so nothing changes but the bytes the half steps stage)
     const bool byt = ctx->knob[KN_X3_BYTES] != 0;
     const bool hbytes = byt, vbytes = byt && v_binary && pieces == 3, nbytes = byt && !gauss;
+    // ... and v_neg^T, the A operand of the statistics GEMM's negative half, where the positive half runs on fp8 planes (the
+    // walk is then whole units of fp8 / 3-piece / 3-piece tiles: k_gemm_pb<..., EPI_SLAB, ..., AB>): 32 KB per 128 k, not 64
+    const bool tbytes = f8pos && nbytes && ctx->knob[KN_X3_STATS_BYTES] != 0 && ctx->knob[KN_X3_STATS_TALL] != 0 && p->n_vis > 128;
     int e;
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
@@ -948,7 +953,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             HalfOutB ho;
             ho.out = w.v2b; ho.ldo = w.Lv; ho.out_pieces = vn_pieces; ho.out_plane = w.planeV; ho.out_bytes = nbytes;
             if (last) {
-                ho.outT = w.v2bT; ho.ldoT = w.Lb; ho.outT_pieces = vn_pieces; ho.outT_plane = w.planeVT;
+                ho.outT = w.v2bT; ho.ldoT = w.Lb; ho.outT_pieces = vn_pieces; ho.outT_plane = w.planeVT; ho.outT_b8 = tbytes;
                 ho.out_f32 = o->v_chain; ho.ldo32 = ldv;
                 ho.grid_m_out = &gm_v;
             }
@@ -1030,6 +1035,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.A0 = w.vbT + (size_t)m_lo * w.Lb; g.a_plane0 = w.planeVT; g.B0 = w.hbT;
         g.A1 = w.v2bT + (size_t)m_lo * w.Lb; g.a_plane1 = w.planeVT; g.B1 = w.hnT; g.b_plane1 = w.planeHT;
         g.lda = w.Lb; g.ldb = w.Lb;
+        if (tbytes) { g.a_bytes = 1; g.lda = 2 * w.Lb; }   // (both A planes hold one byte per element at the bf16 planes' row stride)
         g.M = Mr; g.N = p->n_hid; g.K = w.Kb;
         g.grid_m = pl.gm; g.grid_n = pl.gn;
         g.slab = w.slab; g.slab_stride = slab_stride; g.ld_slab = pl.ld_slab;
@@ -1259,7 +1265,11 @@ int kurbm_x3_dump_plane(kurbm_ctx* ctx, int which, int rows, int n_vis, int n_hi
         case KURBM_PLANE_V_NEG:   a.src = w.v2b;  a.units = n_vis; a.ld = w.Lv; a.fmt = (byt && !gauss) ? 1 : 0;
                                   a.pieces = gauss ? 3 : 1; a.plane = w.planeV; break;
         case KURBM_PLANE_V_NEG_T: a.src = w.v2bT; a.units = n_vis; a.ld = w.Lb; a.transposed = 1;
-                                  a.pieces = gauss ? 3 : 1; a.plane = w.planeVT; break;
+                                  a.pieces = gauss ? 3 : 1; a.plane = w.planeVT;
+                                  if (f8pos && byt && !gauss && ctx->knob[KN_X3_STATS_BYTES] != 0 && ctx->knob[KN_X3_STATS_TALL] != 0 && n_vis > 128) {
+                                      a.fmt = 1; a.ld = 2 * w.Lb;   // (bytes at the bf16 plane's row stride: cd_step_any, tbytes)
+                                  }
+                                  break;
         case KURBM_PLANE_H_NEG_T: a.src = w.hnT;  a.units = n_hid; a.ld = w.Lb; a.transposed = 1; a.pieces = 3; a.plane = w.planeHT;
                                   a.sign = -1.f; break;
         default: return fail(KURBM_ERR_ARG, "unknown plane %d", which);

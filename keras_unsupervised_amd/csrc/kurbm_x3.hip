@@ -128,7 +128,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     static_assert(KS == 2, "fragment buffers alternate with the k-step");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;
-    static_assert(!AB || EPI == EPI_HALFSTEP || EPI == EPI_SOFTPLUS, "byte A tiles: half steps and the free-energy GEMM");
+    // ABS: the statistics GEMM of 0/1 data with BOTH A operands one byte per element -- v_pos^T fp8 (as before), v_neg^T a byte
+    // plane like the half steps' A operand (32 KB per 128 k where the bf16 plane is 64: this launch is bound by the bytes a CU
+    // can take in, ~34 per cycle).  Only the fixed walk fp8 / 3-piece / 3-piece (g.walk3); the fp8 tile is scaled x 2 through
+    // its E8M0 exponent so that the slab epilogue's halving (0x40 bytes are 2.0) leaves it alone.
+    constexpr bool ABS = AB && EPI == EPI_SLAB;
+    static_assert(!ABS || (PB == 3 && !RP), "byte-plane statistics: three-piece negative half");
     constexpr int A_BYTES = BM * ROWB, B1_BYTES = BN * ROWB, B_BYTES = PB * B1_BYTES;   // (AB: A_BYTES is a BLOCK, 128 k deep)
     // DEEP: one-piece tiles of bytes (the rounded-bf16 path's half steps on 0/1 states) -- 16 MFMAs per wave and tile, a third
     // of a DMA round trip -- run a deeper pipeline than the three-piece tiles have room for: FOUR B stages and THREE A blocks,
@@ -636,6 +641,48 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     __builtin_amdgcn_s_barrier();
                 }
                 KURBM_LSTAMP_OUT();
+            } else if constexpr (ABS) {
+                // Unit u = tiles 3 u (fp8), 3 u + 1, 3 u + 2 (three pieces each).  A buffer 0 holds the fp8 block of a unit (its
+                // tile 3 u), buffer 1 the byte block (tiles 3 u + 1 and 3 u + 2); B pieces go to stage (tile & 1).  While tile i
+                // is multiplied the loaders request tile i + 1's B pieces and:   i = 3 u     the byte block of unit u, whole;
+                // i = 3 u + 1   the first half of the rows of fp8 block u + 1 (tile 3 u was its buffer's last reader);
+                // i = 3 u + 2   the second half.
+                TileRef rp = tile_of(t_begin), rn = tile_of(t_begin + 1);
+                TileRef ra = rn;                                 // the byte block: its plane holds 128 k in the 128 bytes a
+                ra.oa = rn.oa >> 1;                              // bf16 plane spends on 64 (piece 0: no plane offset in oa)
+                dma_part(0, rp, 3, 0);                           // tile 0: fp8 A block + its one B piece
+                dma_part(0, ra, 1, 1);                           // byte block of unit 0 ...
+                dma_part(1, rn, 2);                              // ... and tile 1's B pieces
+                __builtin_amdgcn_s_waitcnt(vm(NA + 3 * NB1));
+                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
+                __builtin_amdgcn_s_barrier();
+                int kind = 2;                                    // of tile i + 1
+                rp.oa += 128u; rp.ob += 128u; ra.oa += 128u; rn.ob += 128u;
+                for (int i = 0; i < nt; ++i) {
+                    KURBM_LSTAMP(0);
+                    if (i >= 1 && i + 1 < nt) {
+                        if (kind == 0) {                         // (i = 3 u + 2) next: the fp8 tile of unit u + 1
+                            dma_part((i + 1) & 1, rp, 2);
+                            dma_part(0, rp, 1, 0, NA / 2, NA);
+                            rp.oa += 128u; rp.ob += 128u;
+                        } else if (kind == 1) {                  // (i = 3 u) next: the first 3-piece tile, and its unit's byte block
+                            dma_part(0, ra, 1, 1);
+                            dma_part((i + 1) & 1, rn, 2);
+                            ra.oa += 128u; rn.ob += 128u;
+                        } else {                                 // (i = 3 u + 1) next: the second 3-piece tile
+                            dma_part((i + 1) & 1, rn, 2);
+                            rn.ob += 128u;
+                            if (i + 2 < nt) dma_part(0, rp, 1, 0, 0, NA / 2);
+                        }
+                    }
+                    if (i >= 1) kind = (kind == 2) ? 0 : kind + 1;
+                    KURBM_LSTAMP(1);
+                    __builtin_amdgcn_s_waitcnt(VM0);
+                    KURBM_LSTAMP(2);
+                    __builtin_amdgcn_s_barrier();
+                    KURBM_LSTAMP(3);
+                }
+                KURBM_LSTAMP_OUT();
             } else if constexpr (AB) {
                 // A block j (128 k of bytes) serves tiles 2 j and 2 j + 1; while tile i is multiplied, the B pieces of tile
                 // i + 1 and HALF of block i / 2 + 1 are requested (its buffer was freed by tile 2 (i / 2) - 1)
@@ -784,11 +831,92 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         __syncthreads();
         frag_a(0, 0, fa[0]);
         frag_b(0, 0, 0, fb[0]);
-        expand_a(0);
+        if constexpr (!ABS) expand_a(0);   // (ABS enters an fp8 tile: raw fragments)
         KURBM_STAMP(ts[1]);
         // unrolled by two: the LDS buffers alternate statically
         int i = 0;
-        if constexpr (DEEP) {
+        if constexpr (ABS) {
+            // fp8 / 3-piece / 3-piece in whole units (g.walk3: launch_pb checks); A buffer 0 = the unit's fp8 block, 1 = its byte
+            // block, whose two halves are the two 3-piece tiles.  The expanded fragments of a byte tile live in fa[1], which only
+            // the fp8 tile uses as raw fragments: this kernel has no 16 registers to spare (168 at three waves per SIMD).
+            const unsigned char* const arow = smem + (wm * WM + l15) * ROWB;
+            auto rd_f8 = [&](int ks, afrag (&f)[TM]) __attribute__((always_inline)) {
+                const unsigned char* c = arow + 16 * ((4 * ks + slot) ^ swz);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
+            };
+            auto rd_by = [&](int half, afrag (&f)[TM]) __attribute__((always_inline)) {
+                const unsigned char* c = arow + A_BYTES + 16 * ((4 * half + slot) ^ swz);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
+            };
+            auto expand0 = [&](int ks) __attribute__((always_inline)) {   // fa[0] (16 bytes = both k-steps) -> fa[1] (one k-step as bf16)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const uint32_t lo = ks ? fa[0][mi].z : fa[0][mi].x, hi = ks ? fa[0][mi].w : fa[0][mi].y;
+                    fa[1][mi] = u32x4{__builtin_amdgcn_perm(0u, lo, 0x010C000Cu), __builtin_amdgcn_perm(0u, lo, 0x030C020Cu),
+                                      __builtin_amdgcn_perm(0u, hi, 0x010C000Cu), __builtin_amdgcn_perm(0u, hi, 0x030C020Cu)};
+                }
+            };
+            auto mf = [&](const u32x4 (&b)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[1][mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+            };
+            // entered with fa[0] = chunks 0-3 of the fp8 block, fb[0] = those of the B piece in stage `cur`
+            auto f8t = [&](const int cur) __attribute__((always_inline)) {
+                typedef int i32x8 __attribute__((ext_vector_type(8)));
+                __builtin_amdgcn_sched_barrier(0);
+                rd_f8(1, fa[1]);
+                frag_b(cur, 1, 0, fb[1]);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        const i32x8 a = {(int)fa[0][mi].x, (int)fa[0][mi].y, (int)fa[0][mi].z, (int)fa[0][mi].w,
+                                         (int)fa[1][mi].x, (int)fa[1][mi].y, (int)fa[1][mi].z, (int)fa[1][mi].w};
+                        const i32x8 b = {(int)fb[0][ni].x, (int)fb[0][ni].y, (int)fb[0][ni].z, (int)fb[0][ni].w,
+                                         (int)fb[1][ni].x, (int)fb[1][ni].y, (int)fb[1][ni].z, (int)fb[1][ni].w};
+                        // (A scaled by 2^1: the slab epilogue halves every sum)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[mi][ni], 0, 0, 0, 0x80, 0, 0x7F);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                rd_by(0, fa[0]);
+                frag_b(cur ^ 1, 0, 0, fb[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                expand0(0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // a 3-piece tile of half `half` of the byte block, B pieces in stage `cur`: entered with fa[0] raw, fa[1] = k-step 0
+            // expanded, fb[0] = piece 0 of k-step 0; micro-step u = 3 ks + piece, fragments read two micro-steps ahead
+            auto negt = [&](const int cur, const int half) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u == 0) { frag_b(cur, 0, 1, fb[1]); frag_b(cur, 0, 2, fb[2]); }
+                    if (u == 1) frag_b(cur, 1, 0, fb[0]);
+                    if (u == 2) frag_b(cur, 1, 1, fb[1]);
+                    if (u == 3) frag_b(cur, 1, 2, fb[2]);
+                    if (u == 5) {
+                        __syncthreads();
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (half == 0) rd_by(1, fa[0]); else rd_f8(0, fa[0]);
+                        frag_b(cur ^ 1, 0, 0, fb[0]);
+                    }
+                    mf(fb[u % 3]);
+                    if (u == 2) { __builtin_amdgcn_sched_barrier(0); expand0(1); }
+                    if (u == 5 && half == 0) { __builtin_amdgcn_sched_barrier(0); expand0(0); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for (; i + 5 < nt; i += 6) { f8t(0); negt(1, 0); negt(0, 1); f8t(1); negt(0, 0); negt(1, 1); }
+            if (i < nt) { f8t(0); negt(1, 0); negt(0, 1); }
+        } else if constexpr (DEEP) {
             // (the pre-loop reads above took tile 0's k-step 0; behind barrier P the rest of tile 0, then barrier -1)
             const uint32_t la = (uint32_t)((wm * WM + l15) * ROWB + 16 * (slot ^ swz));            // + block; ^ 64: second tile of the block
             const uint32_t lb = (uint32_t)(B_OFF + (wn * WN + l15) * ROWB + 16 * (slot ^ swz));    // + stage; ^ 64: k-step 1
@@ -922,7 +1050,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 for (int r = 0; r < 4; ++r)
                     *reinterpret_cast<float*>(smem + (wm * WM + mi * 16 + slot * 4 + r) * PROW32 +
                                               4 * (wn * WN + ni * 16 + l15)) =
-                        (n0 + wn * WN + ni * 16 + l15 < g.N) ? acc[mi][ni][r] : 0.f;
+                        (n0 + wn * WN + ni * 16 + l15 < g.N) ? (ABS ? 0.5f * acc[mi][ni][r] : acc[mi][ni][r]) : 0.f;
         __syncthreads();
         constexpr int CH = BN / 4;   // 16-B chunks per row
         if (!g.fuse) {
@@ -1252,6 +1380,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = (rb + r < g.M) ? tsign * xv[mi][ni][r] : 0.f;
+                    if (g.outT_f8 == 2) {   // ... as four bytes of a k-permuted byte plane (0x40 = one; kurbm_device.h kperm64:
+                                            // four consecutive k from a multiple of four stay consecutive), row stride as for bf16
+                        *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(g.outT) + (size_t)col * g.ldoT * 2 + kperm64(rb)) =
+                            (v[0] != 0.f ? 0x40u : 0u) | (v[1] != 0.f ? 0x4000u : 0u) | (v[2] != 0.f ? 0x400000u : 0u) |
+                            (v[3] != 0.f ? 0x40000000u : 0u);
+                        continue;
+                    }
                     if (g.outT_f8) {   // a 0/1 sample as four fp8 bytes (1.0 = 0x38), row stride as for bf16
                         *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(g.outT) + (size_t)col * g.ldoT * 2 + rb) =
                             (v[0] != 0.f ? 0x38u : 0u) | (v[1] != 0.f ? 0x3800u : 0u) | (v[2] != 0.f ? 0x380000u : 0u) |
@@ -1382,7 +1517,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 template <int PBN, int E, int NZ>
 static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
     // byte A planes: ONE segment of PBN pieces, one k slice -- those kernels' loops do not walk a tile list
-    if (g.a_bytes && (g.nseg != 1 || g.nsplit != 1 || (int)((g.seg_codes >> 2) & 3u) != PBN)) return hipErrorInvalidValue;
+    // (the statistics GEMM on byte planes: its own fixed walk, any number of k slices -- checked where it is launched)
+    if (g.a_bytes && E != EPI_SLAB && (g.nseg != 1 || g.nsplit != 1 || (int)((g.seg_codes >> 2) & 3u) != PBN)) return hipErrorInvalidValue;
     if constexpr (E == EPI_HALFSTEP && PBN == 3 && (NZ == NOISE_BERNOULLI || NZ == NOISE_NONE)) {
         if (g.rp) {   // the score's half steps: (samples AND) the softplus row sums of their rows
             if (!g.rowpart) return hipErrorInvalidValue;
@@ -1403,6 +1539,10 @@ static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
             if (g.cfg == 2) KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             else if (g.cfg == 0) KURBM_LAUNCH((k_gemm_pb<128, 128, 2, 4, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             else return hipErrorInvalidValue;
+            return hipGetLastError();
+        } else if constexpr (E == EPI_SLAB && PBN == 3) {
+            if (g.cfg != 2 || !g.walk3) return hipErrorInvalidValue;
+            KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;
