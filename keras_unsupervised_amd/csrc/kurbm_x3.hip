@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // of a DMA round trip -- run a deeper pipeline than the three-piece tiles have room for: FOUR B stages and THREE A blocks,
     // tiles requested four ahead, fragments read two micro-steps (= one tile) ahead ACROSS the tile's barrier (see `deep_tile`)
     constexpr bool DEEP = AB && PB == 1;
-    constexpr int NAB = DEEP ? 3 : 2;     // A block buffers (AB)
+    constexpr int NAB = (DEEP || (AB && EPI == EPI_SLAB)) ? 3 : 2;     // A block buffers (AB)
     // LDS: two stages [A tile | B pieces]; AB: the A blocks, then the stages of B pieces
     constexpr int STAGE = AB ? B_BYTES : A_BYTES + B_BYTES;
     constexpr int B_OFF = AB ? NAB * A_BYTES : A_BYTES;
@@ -152,7 +152,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // stages, tiles requested two ahead.  (Three-piece tiles: two stages fill the LDS.)
     constexpr int NSTG = DEEP ? 4 : (PB == 1) ? 3 : 2;
     // (AB: NAB A blocks of 128 k beside NSTG stages of B pieces, the A blocks requested half a block per tile)
-    constexpr int STAGES_BYTES = AB ? NAB * A_BYTES + NSTG * B_BYTES : NSTG * (A_BYTES + B_BYTES);
+    // (byte-plane statistics: three A blocks, a B stage for each of the two 3-piece tiles of a unit and one PIECE for its fp8 tile)
+    constexpr int STAGES_BYTES = (AB && EPI == EPI_SLAB) ? NAB * A_BYTES + 2 * B_BYTES + B1_BYTES
+                               : AB ? NAB * A_BYTES + NSTG * B_BYTES : NSTG * (A_BYTES + B_BYTES);
     constexpr int SMEM_BYTES = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
     // the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
     // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
@@ -642,45 +644,64 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 }
                 KURBM_LSTAMP_OUT();
             } else if constexpr (ABS) {
-                // Unit u = tiles 3 u (fp8), 3 u + 1, 3 u + 2 (three pieces each).  A buffer 0 holds the fp8 block of a unit (its
-                // tile 3 u), buffer 1 the byte block (tiles 3 u + 1 and 3 u + 2); B pieces go to stage (tile & 1).  While tile i
-                // is multiplied the loaders request tile i + 1's B pieces and:   i = 3 u     the byte block of unit u, whole;
-                // i = 3 u + 1   the first half of the rows of fp8 block u + 1 (tile 3 u was its buffer's last reader);
-                // i = 3 u + 2   the second half.
+                // Unit u = tiles F(u) (fp8), Na(u), Nb(u) (three pieces each, the two halves of the unit's byte block).  The A
+                // blocks rotate through THREE buffers (block 2 u = fp8, 2 u + 1 = bytes; buffer = block % 3); the B pieces of Na go
+                // to stage 0, of Nb to stage 1, the fp8 tile's one piece to "stage" 2 (8 KB).  Every buffer is requested the
+                // moment its last reader has passed its barrier, every request is 40 KB = 10 pieces per wave, and each lands at
+                // least one whole tile before its first reader:
+                //   while F(u) is multiplied:   first half of fp8 block u + 1,  B of Nb(u)
+                //   while Na(u):                first half of byte block u + 1, B of F(u + 1), second half of fp8 block u + 1
+                //   while Nb(u):                B of Na(u + 1),                 second half of byte block u + 1
+                // so the tile's barrier waits for everything but the 10 pieces just requested (a counted vmcnt).
+                static_assert(NA / 2 + 3 * NB1 == 10 && NA + NB1 == 10, "10 pieces per wave and tile");
+                const int nu = nt / 3;
                 TileRef rp = tile_of(t_begin), rn = tile_of(t_begin + 1);
                 TileRef ra = rn;                                 // the byte block: its plane holds 128 k in the 128 bytes a
                 ra.oa = rn.oa >> 1;                              // bf16 plane spends on 64 (piece 0: no plane offset in oa)
-                dma_part(0, rp, 3, 0);                           // tile 0: fp8 A block + its one B piece
-                dma_part(0, ra, 1, 1);                           // byte block of unit 0 ...
-                dma_part(1, rn, 2);                              // ... and tile 1's B pieces
-                __builtin_amdgcn_s_waitcnt(vm(NA + 3 * NB1));
+                int bf = 0, bb = 1;                              // A buffers of fp8 block u / byte block u (u = 0)
+                auto nxt = [](int b, int by) constexpr { return (b + by) % 3; };
+                dma_part(2, rp, 3, bf);                          // F(0): fp8 block 0 + its one B piece
+                dma_part(0, ra, 1, bb);                          // byte block 0
+                dma_part(0, rn, 2);                              // B of Na(0)
+                __builtin_amdgcn_s_waitcnt(vm(NA + 3 * NB1));    // F(0) has landed
                 __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
                 __builtin_amdgcn_s_barrier();
-                int kind = 2;                                    // of tile i + 1
-                rp.oa += 128u; rp.ob += 128u; ra.oa += 128u; rn.ob += 128u;
-                for (int i = 0; i < nt; ++i) {
+                rn.ob += 128u;                                   // -> Nb(0)
+                for (int u = 0; u < nu; ++u) {
+                    const bool more = u + 1 < nu;
+                    const int bf1 = nxt(bf, 2), bb1 = nxt(bb, 2);   // buffers of the next unit's blocks
+                    // ---- F(u) in work
                     KURBM_LSTAMP(0);
-                    if (i >= 1 && i + 1 < nt) {
-                        if (kind == 0) {                         // (i = 3 u + 2) next: the fp8 tile of unit u + 1
-                            dma_part((i + 1) & 1, rp, 2);
-                            dma_part(0, rp, 1, 0, NA / 2, NA);
-                            rp.oa += 128u; rp.ob += 128u;
-                        } else if (kind == 1) {                  // (i = 3 u) next: the first 3-piece tile, and its unit's byte block
-                            dma_part(0, ra, 1, 1);
-                            dma_part((i + 1) & 1, rn, 2);
-                            ra.oa += 128u; rn.ob += 128u;
-                        } else {                                 // (i = 3 u + 1) next: the second 3-piece tile
-                            dma_part((i + 1) & 1, rn, 2);
-                            rn.ob += 128u;
-                            if (i + 2 < nt) dma_part(0, rp, 1, 0, 0, NA / 2);
-                        }
-                    }
-                    if (i >= 1) kind = (kind == 2) ? 0 : kind + 1;
+                    if (more) { rp.oa += 128u; rp.ob += 128u; dma_part(0, rp, 1, bf1, 0, NA / 2); }
+                    dma_part(1, rn, 2);                          // B of Nb(u)
+                    rn.ob += 128u;
                     KURBM_LSTAMP(1);
-                    __builtin_amdgcn_s_waitcnt(VM0);
+                    if (more) __builtin_amdgcn_s_waitcnt(vm(10)); else __builtin_amdgcn_s_waitcnt(vm(3 * NB1));
                     KURBM_LSTAMP(2);
                     __builtin_amdgcn_s_barrier();
                     KURBM_LSTAMP(3);
+                    // ---- Na(u) in work
+                    if (more) {
+                        ra.oa += 128u;
+                        dma_part(0, ra, 1, bb1, 0, NA / 2);
+                        dma_part(2, rp, 2);
+                        dma_part(0, rp, 1, bf1, NA / 2, NA);
+                        __builtin_amdgcn_s_waitcnt(vm(10));
+                    } else {
+                        __builtin_amdgcn_s_waitcnt(VM0);
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    // ---- Nb(u) in work
+                    if (more) {
+                        dma_part(0, rn, 2);                      // B of Na(u + 1)
+                        rn.ob += 128u;
+                        dma_part(0, ra, 1, bb1, NA / 2, NA);
+                        __builtin_amdgcn_s_waitcnt(vm(10));
+                    } else {
+                        __builtin_amdgcn_s_waitcnt(VM0);
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    bf = bf1; bb = bb1;
                 }
                 KURBM_LSTAMP_OUT();
             } else if constexpr (AB) {
@@ -830,25 +851,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     if (nt > 0) {
         __syncthreads();
         frag_a(0, 0, fa[0]);
-        frag_b(0, 0, 0, fb[0]);
+        frag_b(ABS ? 2 : 0, 0, 0, fb[0]);  // (ABS: the fp8 tile's B piece has a stage of its own)
         if constexpr (!ABS) expand_a(0);   // (ABS enters an fp8 tile: raw fragments)
         KURBM_STAMP(ts[1]);
         // unrolled by two: the LDS buffers alternate statically
         int i = 0;
         if constexpr (ABS) {
-            // fp8 / 3-piece / 3-piece in whole units (g.walk3: launch_pb checks); A buffer 0 = the unit's fp8 block, 1 = its byte
-            // block, whose two halves are the two 3-piece tiles.  The expanded fragments of a byte tile live in fa[1], which only
-            // the fp8 tile uses as raw fragments: this kernel has no 16 registers to spare (168 at three waves per SIMD).
-            const unsigned char* const arow = smem + (wm * WM + l15) * ROWB;
-            auto rd_f8 = [&](int ks, afrag (&f)[TM]) __attribute__((always_inline)) {
-                const unsigned char* c = arow + 16 * ((4 * ks + slot) ^ swz);
+            // fp8 / 3-piece / 3-piece in whole units (g.walk3: launch_pb checks); the unit's fp8 block and its byte block (whose two
+            // halves are the two 3-piece tiles) sit in two of three A buffers (the loaders' comment has the ring).  The expanded
+            // fragments of a byte tile live in fa[1], which only the fp8 tile uses as raw fragments.
+            const uint32_t arow = (uint32_t)((wm * WM + l15) * ROWB);
+            uint32_t of8 = 0u, oby = A_BYTES;     // A buffers of the unit's fp8 block / byte block (blocks 2 u, 2 u + 1; buffer = block % 3)
+            auto rd_f8 = [&](uint32_t off, int ks, afrag (&f)[TM]) __attribute__((always_inline)) {
+                const unsigned char* c = smem + (arow + 16 * ((4 * ks + slot) ^ swz) + off);
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
             };
-            auto rd_by = [&](int half, afrag (&f)[TM]) __attribute__((always_inline)) {
-                const unsigned char* c = arow + A_BYTES + 16 * ((4 * half + slot) ^ swz);
+            auto rd_by = [&](uint32_t off, int half, afrag (&f)[TM]) __attribute__((always_inline)) {
+                const unsigned char* c = smem + (arow + 16 * ((4 * half + slot) ^ swz) + off);
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
+            };
+            auto adv = [](uint32_t o) __attribute__((always_inline)) {   // two blocks on in the ring of three
+                return o + 2 * A_BYTES >= 3 * A_BYTES ? o + 2 * A_BYTES - 3 * A_BYTES : o + 2 * A_BYTES;
             };
             auto expand0 = [&](int ks) __attribute__((always_inline)) {   // fa[0] (16 bytes = both k-steps) -> fa[1] (one k-step as bf16)
 #pragma unroll
@@ -866,12 +891,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, fa[1][mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
             };
-            // entered with fa[0] = chunks 0-3 of the fp8 block, fb[0] = those of the B piece in stage `cur`
-            auto f8t = [&](const int cur) __attribute__((always_inline)) {
+            // B stages: 0 = Na, 1 = Nb, 2 = the fp8 tile's piece.  The fp8 tile is entered with fa[0] = chunks 0-3 of its block,
+            // fb[0] = those of its B piece
+            auto f8t = [&]() __attribute__((always_inline)) {
                 typedef int i32x8 __attribute__((ext_vector_type(8)));
                 __builtin_amdgcn_sched_barrier(0);
-                rd_f8(1, fa[1]);
-                frag_b(cur, 1, 0, fb[1]);
+                rd_f8(of8, 1, fa[1]);
+                frag_b(2, 1, 0, fb[1]);
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -886,27 +912,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
-                rd_by(0, fa[0]);
-                frag_b(cur ^ 1, 0, 0, fb[0]);
+                rd_by(oby, 0, fa[0]);
+                frag_b(0, 0, 0, fb[0]);
                 __builtin_amdgcn_sched_barrier(0);
                 expand0(0);
                 __builtin_amdgcn_sched_barrier(0);
             };
-            // a 3-piece tile of half `half` of the byte block, B pieces in stage `cur`: entered with fa[0] raw, fa[1] = k-step 0
-            // expanded, fb[0] = piece 0 of k-step 0; micro-step u = 3 ks + piece, fragments read two micro-steps ahead
-            auto negt = [&](const int cur, const int half) __attribute__((always_inline)) {
+            // a 3-piece tile of half `half` of the byte block, B pieces in stage `half`: entered with fa[0] raw, fa[1] = k-step 0
+            // expanded, fb[0] = piece 0 of k-step 0; micro-step u = 3 ks + piece, fragments read two micro-steps ahead.  `nf8`:
+            // the A buffer of the NEXT unit's fp8 block (behind the second tile)
+            auto negt = [&](const int half, const uint32_t nf8) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < 6; ++u) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (u == 0) { frag_b(cur, 0, 1, fb[1]); frag_b(cur, 0, 2, fb[2]); }
-                    if (u == 1) frag_b(cur, 1, 0, fb[0]);
-                    if (u == 2) frag_b(cur, 1, 1, fb[1]);
-                    if (u == 3) frag_b(cur, 1, 2, fb[2]);
+                    if (u == 0) { frag_b(half, 0, 1, fb[1]); frag_b(half, 0, 2, fb[2]); }
+                    if (u == 1) frag_b(half, 1, 0, fb[0]);
+                    if (u == 2) frag_b(half, 1, 1, fb[1]);
+                    if (u == 3) frag_b(half, 1, 2, fb[2]);
                     if (u == 5) {
                         __syncthreads();
                         __builtin_amdgcn_sched_barrier(0);
-                        if (half == 0) rd_by(1, fa[0]); else rd_f8(0, fa[0]);
-                        frag_b(cur ^ 1, 0, 0, fb[0]);
+                        if (half == 0) { rd_by(oby, 1, fa[0]); frag_b(1, 0, 0, fb[0]); }
+                        else { rd_f8(nf8, 0, fa[0]); frag_b(2, 0, 0, fb[0]); }
                     }
                     mf(fb[u % 3]);
                     if (u == 2) { __builtin_amdgcn_sched_barrier(0); expand0(1); }
@@ -914,8 +941,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            for (; i + 5 < nt; i += 6) { f8t(0); negt(1, 0); negt(0, 1); f8t(1); negt(0, 0); negt(1, 1); }
-            if (i < nt) { f8t(0); negt(1, 0); negt(0, 1); }
+            for (; i + 2 < nt; i += 3) {
+                const uint32_t nf8 = adv(of8);
+                f8t();
+                negt(0, nf8);
+                negt(1, nf8);
+                of8 = nf8; oby = adv(oby);
+            }
         } else if constexpr (DEEP) {
             // (the pre-loop reads above took tile 0's k-step 0; behind barrier P the rest of tile 0, then barrier -1)
             const uint32_t la = (uint32_t)((wm * WM + l15) * ROWB + 16 * (slot ^ swz));            // + block; ^ 64: second tile of the block
