@@ -289,37 +289,60 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // a tile: the scalar byte offsets of its A rows and of piece 0 of its B rows
     struct TileRef { uint32_t oa, ob, bplane, oa_piece; int npb; bool neg, f8; };
     constexpr bool F8 = (EPI == EPI_SLAB && PB == 3);   // the kernel that may meet fp8 tiles (g.f8pos)
-    auto tile_of = [&](int t) __attribute__((always_inline)) {
+    // The tiles of a k slice are walked in order, so a tile is a POSITION: `a` inside a period of `wl_len` tiles, `b` = which
+    // period.  Three walks: segment-major (half steps: a = k-tile, b = segment), segment-fastest (statistics: a = segment,
+    // b = k-tile), and with fp8 positive statistics units of 128 k (a = 0: the fp8 tile of segment 0, then two 64-deep tiles of
+    // every other segment; b = unit).  What a segment contributes -- plane offsets, operand set, piece count -- sits in a table
+    // with one LANE per segment (four registers) and comes out by v_readlane: a step of the walk is a compare and an add, a tile
+    // reference five scalar instructions.  (Until round 3 every tile was decoded from its index in BOTH loops -- two multiply-
+    // highs, 64-bit shifts, a dozen kernel arguments kept live in scalar registers that then spilled: a sixth of the k loop.)
+    struct Walk { int a, b; };
+    const bool wl_f8 = F8 && g.f8pos, wl_sf = g.seg_fastest != 0;
+    const int wl_len = wl_f8 ? 2 * g.nseg - 1 : wl_sf ? g.nseg : g.nkt;
+    uint32_t t_code, t_oa, t_ob, t_bp;
+    {
+        const int sl = lane < g.nseg ? lane : 0;
+        t_code = (uint32_t)(g.seg_codes >> (5 * sl)) & 31u;
+        const bool ng = (t_code & 16u) != 0u;
+        t_oa = 2u * (t_code & 3u) * (uint32_t)(ng ? g.a_plane1 : g.a_plane0);
+        t_ob = ng ? g.offB1 : g.offB0;
+        t_bp = 2u * (uint32_t)(ng ? g.b_plane1 : g.b_plane0);
+    }
+    auto walk_at = [&](int t) __attribute__((always_inline)) {   // (one multiply-high: outside the loops)
+        const uint32_t inv = (wl_f8 || wl_sf) ? g.inv_nseg : g.inv_nkt;      // (0: the period is one tile long)
+        Walk w;
+        w.b = inv ? (int)__umulhi((uint32_t)t, inv) : t;
+        w.a = t - w.b * wl_len;
+        return w;
+    };
+    auto walk_next = [&](Walk& w) __attribute__((always_inline)) {
+        if (++w.a == wl_len) { w.a = 0; ++w.b; }
+    };
+    auto walk_ref = [&](const Walk& w) __attribute__((always_inline)) {
         TileRef r;
-        t = t < t_end ? t : t_end - 1;
         int seg, kt;
         bool f8 = false;
-        if (F8 && g.f8pos) {
-            // units of 128 k: tile 0 = segment 0 on fp8 (128 bytes of a row are 128 k), then two 64-deep tiles per other segment
-            const int per = 2 * g.nseg - 1;
-            const int unit = (int)__umulhi((uint32_t)t, g.inv_nseg), idx = t - unit * per;
-            f8 = (idx == 0);
-            seg = f8 ? 0 : 1 + ((idx - 1) >> 1);
-            kt = f8 ? unit : 2 * unit + ((idx - 1) & 1);
-        } else if (g.seg_fastest) {
-            kt = g.inv_nseg ? (int)__umulhi((uint32_t)t, g.inv_nseg) : t;       // inv == 0: divisor 1
-            seg = t - kt * g.nseg;
+        if (wl_f8) {
+            f8 = (w.a == 0);
+            seg = f8 ? 0 : 1 + ((w.a - 1) >> 1);
+            kt = f8 ? w.b : 2 * w.b + ((w.a - 1) & 1);
+        } else if (wl_sf) {
+            seg = w.a; kt = w.b;
         } else {
-            seg = g.inv_nkt ? (int)__umulhi((uint32_t)t, g.inv_nkt) : t;
-            kt = t - seg * g.nkt;
+            kt = w.a; seg = w.b;
         }
-        const uint32_t code = (uint32_t)(g.seg_codes >> (5 * seg)) & 31u;
-        const bool neg = (code & 16u) != 0u;
+        const uint32_t code = __builtin_amdgcn_readlane(t_code, seg);
         const uint32_t k0 = 2u * (uint32_t)(kt * BKB);   // (128 bytes per k-tile, bf16 or fp8)
-        r.oa = __builtin_amdgcn_readfirstlane(2u * (code & 3u) * (uint32_t)(neg ? g.a_plane1 : g.a_plane0) + k0);   // (AB: unused)
-        r.oa_piece = __builtin_amdgcn_readfirstlane(code & 3u);   // (diagnostic builds)
-        r.neg = __builtin_amdgcn_readfirstlane((int)neg) != 0;
-        r.f8 = __builtin_amdgcn_readfirstlane((int)f8) != 0;
-        r.ob = __builtin_amdgcn_readfirstlane((neg ? g.offB1 : g.offB0) + k0);
-        r.bplane = __builtin_amdgcn_readfirstlane(2u * (uint32_t)(neg ? g.b_plane1 : g.b_plane0));
-        r.npb = __builtin_amdgcn_readfirstlane((int)((code >> 2) & 3u));
+        r.oa = __builtin_amdgcn_readlane(t_oa, seg) + k0;                    // (AB: unused)
+        r.oa_piece = code & 3u;                                              // (diagnostic builds)
+        r.neg = (code & 16u) != 0u;
+        r.f8 = f8;
+        r.ob = __builtin_amdgcn_readlane(t_ob, seg) + k0;
+        r.bplane = __builtin_amdgcn_readlane(t_bp, seg);
+        r.npb = (int)((code >> 2) & 3u);
         return r;
     };
+    auto tile_of = [&](int t) __attribute__((always_inline)) { return walk_ref(walk_at(t)); };
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -739,15 +762,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 // ring of three stages: while tile i is multiplied, tile i + 1 is landing and tile i + 2 is requested into the
                 // stage tile i - 1 has left; a counted vmcnt leaves the youngest tile's pieces in flight across the barrier
                 constexpr int NP = NA + NB1;   // (one-piece tiles: pieces per loader wave and tile)
-                dma_tile(0, tile_of(t_begin));
-                if (nt > 1) dma_tile(1, tile_of(t_begin + 1));
+                Walk w = walk_at(t_begin);
+                dma_tile(0, walk_ref(w)); walk_next(w);
+                if (nt > 1) { dma_tile(1, walk_ref(w)); walk_next(w); }
                 if (nt > 1) __builtin_amdgcn_s_waitcnt(vm(NP)); else __builtin_amdgcn_s_waitcnt(VM0);
                 __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
                 __builtin_amdgcn_s_barrier();
                 int nb = 2;   // stage of tile i + 2
                 for (int i = 0; i < nt; ++i) {
                     if (i + 2 < nt) {
-                        dma_tile(nb, tile_of(t_begin + i + 2));
+                        dma_tile(nb, walk_ref(w)); walk_next(w);
                         __builtin_amdgcn_s_waitcnt(vm(NP));
                     } else {
                         __builtin_amdgcn_s_waitcnt(VM0);
@@ -758,9 +782,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             } else {
             // both stages are free at the start: tiles 0 and 1 are requested back to back, and the first barrier waits for
             // tile 0's pieces only (a counted vmcnt leaves tile 1's in flight)
-            dma_tile(0, tile_of(t_begin));
+            Walk w = walk_at(t_begin);
+            dma_tile(0, walk_ref(w)); walk_next(w);
             if (nt > 1) {
-                const TileRef t1 = tile_of(t_begin + 1);
+                const TileRef t1 = walk_ref(w);
+                walk_next(w);                                   // (w: tile 2)
                 dma_tile(1, t1);
                 if (t1.npb >= 3) __builtin_amdgcn_s_waitcnt(vm(NA + 3 * NB1));
                 else if (t1.npb == 2) __builtin_amdgcn_s_waitcnt(vm(NA + 2 * NB1));
@@ -793,7 +819,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             } else {
             for (int i = 0; i < nt; ++i) {
                 KURBM_LSTAMP(0);
-                if (i >= 1 && i + 1 < nt) dma_tile((i + 1) & 1, tile_of(t_begin + i + 1));
+                if (i >= 1 && i + 1 < nt) { dma_tile((i + 1) & 1, walk_ref(w)); walk_next(w); }
                 KURBM_LSTAMP(1);
                 __builtin_amdgcn_s_waitcnt(VM0);
                 KURBM_LSTAMP(2);
@@ -1024,13 +1050,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             }
             if (i < nt) deep_tile(std::integral_constant<int, 0>{});
         } else if constexpr (NSTG == 3) {
+            Walk w = walk_at(t_begin);
             for (; i + 2 < nt; i += 3) {
-                tile_any(0, 0, tile_of(t_begin + i));
-                tile_any(1, 0, tile_of(t_begin + i + 1));
-                tile_any(2, 0, tile_of(t_begin + i + 2));
+                tile_any(0, 0, walk_ref(w)); walk_next(w);
+                tile_any(1, 0, walk_ref(w)); walk_next(w);
+                tile_any(2, 0, walk_ref(w)); walk_next(w);
             }
-            if (i < nt) tile_any(0, 0, tile_of(t_begin + i));
-            if (i + 1 < nt) tile_any(1, 0, tile_of(t_begin + i + 1));
+            if (i < nt) { tile_any(0, 0, walk_ref(w)); walk_next(w); }
+            if (i + 1 < nt) tile_any(1, 0, walk_ref(w));
         } else {
             if constexpr (AB) {
                 // one segment of PB pieces (launch_pb checks): every tile is the same tile -- no tile list, no dispatch
@@ -1057,12 +1084,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                         one_tile(0, 0, std::integral_constant<int, 3>{});
                     }
                 } else {
+                Walk w = walk_at(t_begin);
                 for (; i + 1 < nt; i += 2) {
-                    tile_any(0, 0, tile_of(t_begin + i));
-                    tile_any(1, 1, tile_of(t_begin + i + 1));
+                    tile_any(0, 0, walk_ref(w)); walk_next(w);
+                    tile_any(1, 1, walk_ref(w)); walk_next(w);
                     ablk ^= 1;
                 }
-                if (i < nt) tile_any(0, 0, tile_of(t_begin + i));
+                if (i < nt) tile_any(0, 0, walk_ref(w));
                 }
             }
         }
