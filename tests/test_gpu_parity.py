@@ -1284,6 +1284,43 @@ def test_fused_slab_reduction_is_bit_identical(gpu_device, ctx_option, cfg):
     assert np.all(np.isfinite(got[1][0])) and not np.array_equal(got[1][0], W0[0])
 
 
+@pytest.mark.parametrize("cfg", [dict(B=4096, nv=784, nh=1024), dict(B=4096, nv=784, nh=1024, planes=True, steps=3),
+                                 dict(B=1024, nv=784, nh=256), dict(B=512, nv=300, nh=200), dict(B=384, nv=260, nh=70),
+                                 dict(B=640, nv=784, nh=1024, k=2, persistent=True), dict(B=4096, nv=784, nh=1024, split=3),
+                                 dict(B=4096, nv=784, nh=1024, split=1), dict(B=2048, nv=1500, nh=333, split=2)])
+def test_stats_byte_plane_is_bit_identical(gpu_device, ctx_option, cfg):
+    """The statistics GEMM with v_neg^T as a byte plane (KURBM_X3_STATS_BYTES=1, the default wherever the positive half runs on
+    fp8 planes: k_gemm_pb<..., EPI_SLAB, ..., AB>, its own tile schedule) against the same launch on the bf16 plane: bytes are
+    2.0 behind a zero low byte, the fp8 tile is scaled by 2 through its exponent and the slab epilogue halves -- powers of two,
+    the same products summed in the same order -- so W, b_h, b_v and the weight-piece mirror are bit for bit the same.
+    rbm.py:125-134."""
+    B, nv, nh = cfg["B"], cfg["nv"], cfg["nh"]
+    steps = cfg.get("steps", 2)
+    mode = O.MODE_VISIBLE_BERNOULLI
+    if "split" in cfg:
+        ctx_option("KURBM_BF16_SPLIT", cfg["split"], -1)
+    W0 = synthetic_params(nv, nh, seed=2300 + B)
+    V = synthetic_binary(B, nv, seed=2301 + B, p=0.3)
+    got = {}
+    for byt in (1, 0):
+        ctx_option("KURBM_X3_STATS_BYTES", byt, 1)
+        e = _engine(*W0, gpu_device)
+        vd = _dm(V, gpu_device)
+        e.workspace_bf16(B, cfg.get("k", 1), 3, e._x3_pieces(vd, None, mode)).fill_(0xFF if byt else 0)
+        chain = None
+        if cfg.get("persistent"):
+            from keras_unsupervised_amd.ebm.engine import DeviceMatrix
+            chain = DeviceMatrix.from_host(synthetic_binary(B, nv, seed=2302 + B, p=0.5), gpu_device)
+        planes = e.make_planes(vd, [(0, B)], mode, chain) if cfg.get("planes") else None
+        for step in range(steps):
+            e.cd_step(vd, B, 0, 1e-3, 9, step, k=cfg.get("k", 1), mode=mode, compute="x3", planes=planes, v_chain=chain)
+        torch.cuda.synchronize()
+        got[byt] = [x.copy() for x in e.get_weights()] + [e._mirrors[3][0].cpu().numpy().copy()]
+    for a, b in zip(got[1], got[0]):
+        assert np.array_equal(a, b)
+    assert np.all(np.isfinite(got[1][0])) and not np.array_equal(got[1][0], W0[0])
+
+
 @pytest.mark.parametrize("cfg", [dict(B=300, nv=784, nh=256, k=1, chunks=(1, 2, 3)), dict(B=260, nv=1100, nh=200, k=2, pcd=True, chunks=(1, 3)),
                                  dict(B=256, nv=2048, nh=2048, k=1, chunks=(0, 4), auto=2), dict(B=128, nv=300, nh=150, k=1, chunks=(2,))])
 def test_bf16_dp_step_one_call(gpu_device, one_rank_comm, cfg):

@@ -23,6 +23,7 @@ LABEL = {
     ("k_gemm_pb<128, 128, 2, 4, 64, 3, 1, 0, true>", 224): "x3_stats_gemm",      # (rounds 1-2a: last argument = wave-specialised)
     ("k_gemm_pb<128, 128, 2, 4, 64, 3, 1, 0, false>", 224): "x3_stats_gemm",     # (since: last argument = A is a byte plane)
     ("k_gemm_pb<256, 64, 4, 2, 64, 3, 1, 0, false>", 256): "x3_stats_gemm",      # (256 x 64 statistics tiles)
+    ("k_gemm_pb<256, 64, 4, 2, 64, 3, 1, 0, true>", 256): "x3_stats_gemm",       # (... with v_neg^T as a byte plane)
 }
 out = collections.defaultdict(dict)
 for path in sys.argv[2:]:

@@ -41,7 +41,8 @@ for ws in ("", ", true", ", false"):
 label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true>", 256)] = "x3_half_step_vh_sample"
 label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true>", 224)] = "x3_half_step_hv_sample"
 label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 0, true>", 256)] = "x3_half_step_vh_prob"
-label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 1, 0, false>", 256)] = "x3_stats_gemm"     # (256 x 64 statistics tiles)
+label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 1, 0, false>", 256)] = "x3_stats_gemm"
+label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 1, 0, true>", 256)] = "x3_stats_gemm"      # (... with v_neg^T as a byte plane)     # (256 x 64 statistics tiles)
 for nz, wgs, name in ((1, 256, "x3_half_step_vh_sample"), (1, 224, "x3_half_step_hv_sample"), (0, 256, "x3_half_step_vh_prob")):
     label[("k_gemm_pb<256, 64, 4, 2, 64, 3, 0, %d, false>" % nz, wgs)] = name      # (real-valued A operand: bf16 planes)
 out = {}
