@@ -94,8 +94,8 @@ class RBM(object):
         # how the matrix products of fit() run (extension; storage, accumulation and results are fp32 in all):
         #   'fp32'  fp32 MFMA               'x3'  fp32 values as exact bf16 triples on the bf16 MFMA
         #   'bf16'  operands ROUNDED to bf16 (reduced precision, BASELINE.json config 5)
-        #   'auto'  (default) 'x3' at batch sizes >= 512, else 'fp32' (tools/bench_fit.py, 784 x 1024, us per step fp32 / x3:
-        #           batch 256 95 / 98, 512 101 / 97, 1024 120 / 105, 4096 332 / 141)
+        #   'auto'  (default) 'x3' at batch sizes >= 256, else 'fp32' (tools/bench_fit.py, 784 x 1024, us per step fp32 / x3,
+        #           end of round 3: batch 256 95 / 87, 512 102 / 87, 1024 122 / 95, 2048 194 / 105, 4096 341 / 129)
         self.compute_dtype = str(opt("compute_dtype", "auto"))
         if self.compute_dtype not in ("fp32", "x3", "bf16", "auto"):
             raise ValueError("compute_dtype must be 'fp32', 'x3', 'bf16' or 'auto'")
@@ -364,7 +364,7 @@ class RBM(object):
 
     def _compute(self):
         if self.compute_dtype == "auto":
-            return "x3" if int(self.hps["batch_size"]) >= 512 else "fp32"
+            return "x3" if int(self.hps["batch_size"]) >= 256 else "fp32"
         return self.compute_dtype
 
     def _update_local(self, Vd, lo, rows, lr, step):
