@@ -67,6 +67,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef KURBM_PRIO_LOADER
 #define KURBM_PRIO_LOADER 0
 #endif
+#ifndef KURBM_T16
+#define KURBM_T16 1           // 0: the transposed byte planes leave in 4-byte stores (A/B builds)
+#endif
 #ifndef KURBM_PRIO_ENTRY
 #define KURBM_PRIO_ENTRY 3    // the loader waves' priority from the kernel's first instruction to their first barrier (0: A/B builds)
 #endif
@@ -1427,7 +1430,87 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #endif
     // (b) transposed bf16 plane(s) [N][ldoT]: 4 consecutive rows of this lane's column = one 8-byte store;
     //     rows past M (k padding of the statistics GEMM) are written as zeros
-    if (g.outT) {
+    if (KURBM_T16 && g.outT && g.outT_f8 && TM == 4) {
+        // A 0/1 sample as ONE byte per element (fp8 1.0 = 0x38, or 0x40 of a k-permuted byte plane).  A lane holds four bytes
+        // (four rows) per 16-row block mi; a 4 x 4 transpose between the block index and the lane's row group (two
+        // v_permlane32_swap + two v_permlane16_swap) gives it 16 CONSECUTIVE rows of its column instead: per column of the
+        // wave's tile one 64-byte run per store instruction where there were four 16-byte pieces in four instructions -- a
+        // quarter of the partial cache lines this epilogue touches (its stores were issue-bound on exactly that: 3 600 cycles).
+        const uint32_t one = (g.outT_f8 == 2) ? 0x40u : 0x38u;
+        const int rq16 = rowq + slot * 12;             // m0 + wm WM + 16 slot
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = colb + ni * 16;
+            uint32_t pk[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int rb = rowq + mi * 16;
+                pk[mi] = 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rb + r < g.M && xv[mi][ni][r] != 0.f) pk[mi] |= one << (8 * r);
+            }
+            {   // (every lane takes part: the swaps sit outside the bounds checks)
+                auto s0 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+                auto s2 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);
+                auto s3 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);
+                pk[0] = s2[0]; pk[1] = s2[1]; pk[2] = s3[0]; pk[3] = s3[1];
+            }
+            if (col < g.N && rq16 < g.ldoT) {
+                unsigned char* dst = reinterpret_cast<unsigned char*>(g.outT) + (size_t)col * g.ldoT * 2;
+                if (g.outT_f8 == 2) {   // (kperm64: eight consecutive k from a multiple of eight stay consecutive)
+                    *reinterpret_cast<u32x2*>(dst + kperm64(rq16)) = u32x2{pk[0], pk[1]};
+                    *reinterpret_cast<u32x2*>(dst + kperm64(rq16 + 8)) = u32x2{pk[2], pk[3]};
+                } else {
+                    *reinterpret_cast<u32x4*>(dst + rq16) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                }
+            }
+        }
+    } else if (KURBM_T16 && g.outT && !g.outT_f8 && TM == 4) {
+        // bf16 pieces: the same transpose on the two dwords of a lane's four rows -- 16 consecutive rows = 32 bytes per lane and
+        // piece, a whole 128-byte line per column of the wave's tile in two 16-byte stores where there were four 8-byte ones
+        const int np = (g.outT_pieces == 3) ? 3 : 1;
+        const float tsign = g.outT_neg ? -1.f : 1.f;   // (the pieces of -x are minus the pieces of x)
+        const int rq16 = rowq + slot * 12;             // m0 + wm WM + 16 slot
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = colb + ni * 16;
+            float v[4][4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[mi][r] = (rowq + mi * 16 + r < g.M) ? tsign * xv[mi][ni][r] : 0.f;
+            for (int j = 0; j < np; ++j) {
+                uint32_t px[4], py[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    px[mi] = pack_bf16x2(v[mi][0], v[mi][1]); py[mi] = pack_bf16x2(v[mi][2], v[mi][3]);
+                    if (j + 1 < np) {   // residual of the piece just packed: exact in fp32
+                        v[mi][0] -= bf16_bits_to_f32(px[mi] & 0xFFFFu); v[mi][1] -= bf16_bits_to_f32(px[mi] >> 16);
+                        v[mi][2] -= bf16_bits_to_f32(py[mi] & 0xFFFFu); v[mi][3] -= bf16_bits_to_f32(py[mi] >> 16);
+                    }
+                }
+                {   // (every lane takes part: the swaps sit outside the bounds checks)
+                    auto a0 = __builtin_amdgcn_permlane32_swap(px[0], px[2], false, false);
+                    auto a1 = __builtin_amdgcn_permlane32_swap(px[1], px[3], false, false);
+                    auto a2 = __builtin_amdgcn_permlane16_swap(a0[0], a1[0], false, false);
+                    auto a3 = __builtin_amdgcn_permlane16_swap(a0[1], a1[1], false, false);
+                    px[0] = a2[0]; px[1] = a2[1]; px[2] = a3[0]; px[3] = a3[1];
+                    auto b0 = __builtin_amdgcn_permlane32_swap(py[0], py[2], false, false);
+                    auto b1 = __builtin_amdgcn_permlane32_swap(py[1], py[3], false, false);
+                    auto b2 = __builtin_amdgcn_permlane16_swap(b0[0], b1[0], false, false);
+                    auto b3 = __builtin_amdgcn_permlane16_swap(b0[1], b1[1], false, false);
+                    py[0] = b2[0]; py[1] = b2[1]; py[2] = b3[0]; py[3] = b3[1];
+                }
+                if (col < g.N && rq16 < g.ldoT) {
+                    uint16_t* dst = g.outT + (size_t)j * g.outT_plane + (size_t)col * g.ldoT + rq16;
+                    *reinterpret_cast<u32x4*>(dst) = u32x4{px[0], py[0], px[1], py[1]};
+                    *reinterpret_cast<u32x4*>(dst + 8) = u32x4{px[2], py[2], px[3], py[3]};
+                }
+            }
+        }
+    } else if (g.outT) {
         const int np = (g.outT_pieces == 3) ? 3 : 1;
         const float tsign = g.outT_neg ? -1.f : 1.f;   // (the pieces of -x are minus the pieces of x)
 #pragma unroll
