@@ -1,4 +1,5 @@
 # A/B: the kernel-argument warm-up at kernel entry (libkurbm.so) against the build without it
+# (make -C keras_unsupervised_amd/csrc variant VAR="-DKURBM_WARM_ARGS=0 -DKURBM_PRIO_ENTRY=0" OUT=libkurbm_nowarm.so)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03z}; mkdir -p $O; cd $R
 C=$R/keras_unsupervised_amd/csrc
