@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_COUNT };
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
@@ -41,6 +41,8 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_ANYORDER", 0},         // TIMING ONLY (results race): bit 0 the half steps, bit 1 the statistics GEMM are launched without
                                    // the AQL barrier bit -- the upper bound of what overlapping dependent launches could gain
     {"KURBM_X3_STATS_BYTES", 1},   // 0: v_neg^T reaches the statistics GEMM as a bf16 plane (1: as bytes where the positive half is fp8)
+    {"KURBM_MAP_SLOW", 0},         // 1: k_gemm_pb maps its blocks by integer division (the path of grids too large for the multiply-high
+                                   //    constants: tests)
 };
 
 struct kurbm_ctx {
@@ -798,7 +800,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         // (the operand loaded straight into registers, one tile ahead) stay in that XCD's L2
         g.m_fastest = ctx->knob[KN_X3_MFAST];
         if (o.grid_m_out) *o.grid_m_out = ceil_div(rows, 128);   // (in 128-row units whatever the tile)
-        g.xcd2d = ctx->knob[KN_X3_XCD2D];
+        g.xcd2d = ctx->knob[KN_X3_XCD2D]; g.map_force = ctx->knob[KN_MAP_SLOW];
         g.any_order = ctx->knob[KN_ANYORDER] & 1;
         HIP_TRY(launch_gemm_pb(EPI_HALFSTEP, g, st));
         return KURBM_OK;
@@ -1049,7 +1051,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.cfg = pl.cfg;
         g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
         g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
-        g.xcd2d = ctx->knob[KN_X3_XCD2D];
+        g.xcd2d = ctx->knob[KN_X3_XCD2D]; g.map_force = ctx->knob[KN_MAP_SLOW];
         g.any_order = (ctx->knob[KN_ANYORDER] >> 1) & 1;
         if (fuse) {
             g.fuse = 1; g.sync = w.sync; g.status = ctx->status; g.red = a;
@@ -1171,7 +1173,7 @@ int kurbm_free_energy_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, si
     g.m_fastest = 1;
     g.bias = p->b_h;
     g.rowpart = reinterpret_cast<float*>(static_cast<char*>(workspace) + a_bytes);
-    g.xcd2d = ctx->knob[KN_X3_XCD2D];
+    g.xcd2d = ctx->knob[KN_X3_XCD2D]; g.map_force = ctx->knob[KN_MAP_SLOW];
     HIP_TRY(launch_gemm_pb(EPI_SOFTPLUS, g, st));
     FinishArgs f;
     f.v = v; f.b_v = p->b_v; f.rowpart = g.rowpart; f.F = F;

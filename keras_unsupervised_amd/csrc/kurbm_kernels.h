@@ -204,6 +204,7 @@ struct GemmArgsB {
     // (launcher) the block mapping's divisions as shifts and multiply-high (divisors < 2^16, dividends < 2^16: exact): a wave's
     // way to its first request for data was ~600 instructions of set-up, and eight integer divisions were a third of them
     uint32_t map_inv_a, map_inv_b;      // ceil(2^32 / d): d = rl cl, then rl (m fastest) or cl | linear order: d = grid_m grid_n, then grid_m or grid_n
+                                        // (exact while dividend x divisor < 2^32; the launcher sets map_slow = 1 for a grid beyond that)
     int map_lrc, map_lxc;               // log2 (xcd_r xcd_c), log2 xcd_c
     int map_rl, map_cl, map_zl;         // row tiles / column tiles / k slices per XCD block
     // k_gemm_pb: XCD-aware 2-D blocks (set by the launcher; xcd_r == 0: the linear order).  The 8 XCDs form a
@@ -226,6 +227,7 @@ struct GemmArgsB {
     int grid_m, grid_n;
     int m_fastest;
     int a_bytes;          // the A operand is such a byte plane (lda bytes between its rows; one segment): k_gemm_pb<..., AB>
+    int map_slow;         // (launcher) 1: the block mapping divides (a grid too large for the multiply-high constants)
     int walk3;            // (launcher) f8pos with ONE other segment of three pieces: the tiles go fp8, 3-piece, 3-piece, ... in whole
                           // units per k slice, and both loops of the statistics kernel step through that pattern instead of decoding a tile list
     // ---- the rest
@@ -265,6 +267,7 @@ struct GemmArgsB {
     float* slab;
     size_t slab_stride;
     int ld_slab;
+    int map_force;        // caller: 1 = map blocks by division whatever the grid (ctx knob KURBM_MAP_SLOW: tests of that path)
     int any_order;        // caller: TIMING ONLY -- launch without the AQL barrier bit (ctx knob KURBM_ANYORDER); results race
     int xcd2d;            // caller: 1 = let the launcher pick such blocks (ctx knob KURBM_X3_XCD2D), 0 = the linear order
     // softplus epilogue (k_gemm_pb, free energy): rowpart[bn][row] = sum over the tile's columns of softplus(x + bias)

@@ -82,6 +82,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // gives each of its slices 4 rows, not one of them 16.
 // x / d through the launcher's ceil(2^32 / d) (x, d < 2^16: exact; inv == 0 stands for d = 1)
 __device__ __forceinline__ int div_magic(int x, uint32_t inv) { return inv ? (int)__umulhi((uint32_t)x, inv) : x; }
+// (slow = 1: a grid beyond the constants' exact range -- launch_gemm_pb -- pays for the division)
+__device__ __forceinline__ int div_map(int x, int d, uint32_t inv, int slow) { return slow ? x / d : div_magic(x, inv); }
 
 struct FuseRows { int lo, hi; };
 __device__ __forceinline__ FuseRows fuse_rows(const GemmArgsB& g, int m0, int z) {
@@ -234,8 +236,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         const int xcd = bid & 7, idx = bid >> 3;
         const int xz = xcd >> g.map_lrc, xr = (xcd & ((1 << g.map_lrc) - 1)) >> g.map_lxc, xc = xcd & ((1 << g.map_lxc) - 1);
         const int rl = g.map_rl, cl = g.map_cl;
-        const int zi = div_magic(idx, g.map_inv_a), t2 = idx - zi * (rl * cl);
-        const int q2 = div_magic(t2, g.map_inv_b);          // t2 / rl (m fastest) or t2 / cl
+        const int zi = div_map(idx, rl * cl, g.map_inv_a, g.map_slow), t2 = idx - zi * (rl * cl);
+        const int q2 = div_map(t2, g.m_fastest ? rl : cl, g.map_inv_b, g.map_slow);   // t2 / rl (m fastest) or t2 / cl
         const int ri = g.m_fastest ? t2 - q2 * rl : q2;
         const int ci = g.m_fastest ? q2 : t2 - q2 * cl;
         z = xz * g.map_zl + zi; bm = xr * rl + ri; bn = xc * cl + ci;
@@ -245,9 +247,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
         }
         const int tiles_mn = g.grid_m * g.grid_n;
-        z = div_magic(bid, g.map_inv_a);
+        z = div_map(bid, tiles_mn, g.map_inv_a, g.map_slow);
         const int tmn = bid - z * tiles_mn;
-        const int q2 = div_magic(tmn, g.map_inv_b);        // tmn / grid_m (m fastest) or tmn / grid_n
+        const int q2 = div_map(tmn, g.m_fastest ? g.grid_m : g.grid_n, g.map_inv_b, g.map_slow);   // tmn / grid_m (m fastest) or tmn / grid_n
         bm = g.m_fastest ? tmn - q2 * g.grid_m : q2;
         bn = g.m_fastest ? q2 : tmn - q2 * g.grid_n;
     }
@@ -1742,8 +1744,25 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     }
     g.walk3 = (epi == EPI_SLAB && g.pb_max == 3 && g.f8pos && g.nseg == 2 && ((g.seg_codes >> 7) & 3u) == 3u &&
                g.kt_per_split % 3 == 0 && g.kt_total % 3 == 0) ? 1 : 0;
-    {   // the block mapping's divisors as multiply-high constants (exact for dividends and divisors below 2^16)
-        if (nblk <= 0 || nblk >= 65536) return hipErrorInvalidValue;
+    {   // the block mapping's divisors as multiply-high constants: exact while dividend x divisor < 2^32 (every grid of the
+        // BASELINE configs by orders of magnitude); beyond that the kernel divides
+        if (nblk <= 0) return hipErrorInvalidValue;
+        {
+            const unsigned long long lim = 0xFFFFFFFFull;
+            unsigned long long worst;
+            if (g.xcd_r) {
+                const unsigned long long rl = (unsigned long long)(g.grid_m / g.xcd_r), cl = (unsigned long long)(g.grid_n / g.xcd_c);
+                worst = (unsigned long long)(nblk / 8 + 1) * (rl * cl);
+                const unsigned long long w2 = (rl * cl) * (rl > cl ? rl : cl);
+                if (w2 > worst) worst = w2;
+            } else {
+                const unsigned long long tm = (unsigned long long)g.grid_m * (unsigned long long)g.grid_n;
+                worst = (unsigned long long)nblk * tm;
+                const unsigned long long w2 = tm * (unsigned long long)(g.grid_m > g.grid_n ? g.grid_m : g.grid_n);
+                if (w2 > worst) worst = w2;
+            }
+            g.map_slow = (worst >= lim || g.map_force) ? 1 : 0;
+        }
         auto inv = [](int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); };   // d = 1: 2^32 wraps to 0, which div_magic reads as "divisor 1"
         if (g.xcd_r) {
             const int rc = g.xcd_r * g.xcd_c;

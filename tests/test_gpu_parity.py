@@ -1284,6 +1284,32 @@ def test_fused_slab_reduction_is_bit_identical(gpu_device, ctx_option, cfg):
     assert np.all(np.isfinite(got[1][0])) and not np.array_equal(got[1][0], W0[0])
 
 
+@pytest.mark.parametrize("cfg", [dict(B=4096, nv=784, nh=1024), dict(B=1024, nv=784, nh=256, xcd2d=0), dict(B=512, nv=300, nh=200),
+                                 dict(B=1024, nv=1024, nh=1024, compute="bf16"), dict(B=2048, nv=1024, nh=784, real=True, xcd2d=0)])
+def test_block_mapping_by_division_is_the_same_mapping(gpu_device, ctx_option, cfg):
+    """k_gemm_pb finds its tile from its block index with multiply-high constants of the launcher (exact while dividend x
+    divisor < 2^32); a grid beyond that takes the same mapping by integer division (GemmArgsB::map_slow).  KURBM_MAP_SLOW=1 forces
+    that path on ordinary grids, in the XCD-block order and in the linear one: the step must come out bit for bit the same."""
+    B, nv, nh = cfg["B"], cfg["nv"], cfg["nh"]
+    compute = cfg.get("compute", "x3")
+    if "xcd2d" in cfg:
+        ctx_option("KURBM_X3_XCD2D", cfg["xcd2d"], 1)
+    W0 = synthetic_params(nv, nh, seed=2400 + B)
+    V = synthetic_real(B, nv, seed=2401 + B) if cfg.get("real") else synthetic_binary(B, nv, seed=2401 + B, p=0.3)
+    got = {}
+    for slow in (1, 0):
+        ctx_option("KURBM_MAP_SLOW", slow, 0)
+        e = _engine(*W0, gpu_device)
+        vd = _dm(V, gpu_device)
+        for step in range(2):
+            e.cd_step(vd, B, 0, 1e-3, 9, step, compute=compute)
+        torch.cuda.synchronize()
+        got[slow] = [x.copy() for x in e.get_weights()]
+    for a, b in zip(got[1], got[0]):
+        assert np.array_equal(a, b)
+    assert np.all(np.isfinite(got[1][0])) and not np.array_equal(got[1][0], W0[0])
+
+
 @pytest.mark.parametrize("cfg", [dict(B=4096, nv=784, nh=1024), dict(B=4096, nv=784, nh=1024, planes=True, steps=3),
                                  dict(B=1024, nv=784, nh=256), dict(B=512, nv=300, nh=200), dict(B=384, nv=260, nh=70),
                                  dict(B=640, nv=784, nh=1024, k=2, persistent=True), dict(B=4096, nv=784, nh=1024, split=3),
