@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_COUNT };
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_BSHARE, KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
@@ -43,6 +43,7 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_X3_STATS_BYTES", 1},   // 0: v_neg^T reaches the statistics GEMM as a bf16 plane (1: as bytes where the positive half is fp8)
     {"KURBM_MAP_SLOW", 0},         // 1: k_gemm_pb maps its blocks by integer division (the path of grids too large for the multiply-high
                                    //    constants: tests)
+    {"KURBM_X3_BSHARE", 1},        // 0: the three segments of a real-valued A operand one after the other, each staging its own B pieces
 };
 
 struct kurbm_ctx {
@@ -766,6 +767,9 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         // x3: one A tile against the three pieces of the weight tile (kurbm_x3.hip); rounded bf16: against its one piece
         g.nseg = pb_codes(ctx, a_pieces, m.pieces, 0u, &g.seg_codes, 0);
         g.pb_max = m.pieces;
+        // a real-valued A operand: its three segments per k position, so that they can share one staging of the B pieces
+        // (k_gemm_pb, "BSH"; launch_gemm_pb checks the pattern)
+        if (g.nseg == 3 && ctx->knob[KN_X3_BSHARE]) { g.seg_fastest = 1; g.inv_nseg = inv_of(3); }
         g.a_bytes = a_bytes ? 1 : 0;   // (a byte plane of 0/1 values: one piece, lda bytes between its rows)
         g.cfg = 0;
         // 2: 256 x 64 tiles (fewer bytes per k-tile).  Whole 256-row tiles only: the bias partial rows are laid out

@@ -227,6 +227,8 @@ struct GemmArgsB {
     int grid_m, grid_n;
     int m_fastest;
     int a_bytes;          // the A operand is such a byte plane (lda bytes between its rows; one segment): k_gemm_pb<..., AB>
+    int bshare;           // (launcher) a real-valued A operand on three-piece weights: segments (A piece p) x (B pieces 0 .. 2 - p), walked
+                          // segment-fastest -- the three tiles of a k position share ONE staging of its B pieces (k_gemm_pb, "BSH")
     int map_slow;         // (launcher) 1: the block mapping divides (a grid too large for the multiply-high constants)
     int walk3;            // (launcher) f8pos with ONE other segment of three pieces: the tiles go fp8, 3-piece, 3-piece, ... in whole
                           // units per k slice, and both loops of the statistics kernel step through that pattern instead of decoding a tile list

@@ -160,10 +160,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // (byte-plane statistics: three A blocks, a B stage for each of the two 3-piece tiles of a unit and one PIECE for its fp8 tile)
     constexpr int STAGES_BYTES = (AB && EPI == EPI_SLAB) ? NAB * A_BYTES + 2 * B_BYTES + B1_BYTES
                                : AB ? NAB * A_BYTES + NSTG * B_BYTES : NSTG * (A_BYTES + B_BYTES);
-    constexpr int SMEM_BYTES = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
+    // BSH (g.bshare; non-AB three-piece half steps: a real-valued A operand): THREE A stages and two B stages -- the three tiles
+    // of a k position (A piece 0 x B pieces 0-2, piece 1 x 0-1, piece 2 x 0) share one staging of that position's B pieces:
+    // 120 instead of 144 KB per k position, and the third A stage lets a counted vmcnt keep a tile in flight across the barrier
+    // (with two [A | B] stages the loaders waited for the tile they had just requested: issue + landing = the tile's time).
+    constexpr bool BSH = !AB && PB == 3 && EPI == EPI_HALFSTEP;
+    constexpr int BSH_BYTES = 3 * A_BYTES + 2 * B_BYTES, BSH_BOFF = 3 * A_BYTES;
+    constexpr int SMEM_BYTES0 = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
+    constexpr int SMEM_BYTES = (BSH && BSH_BYTES > SMEM_BYTES0) ? BSH_BYTES : SMEM_BYTES0;
     // the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
     // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
-    constexpr int NI_LDS = (EPI == EPI_HALFSTEP && NOISE == NOISE_BERNOULLI) ? 1 : 0;
+    // (none beside the BSH layout: 144 of the 160 KB)
+    constexpr int NI_LDS = (EPI == EPI_HALFSTEP && NOISE == NOISE_BERNOULLI && !BSH) ? 1 : 0;
     constexpr int DRAW_LDS_BYTES = NI_LDS * TM * NT * 16;
     // EPI_SLAB, fused reduction: behind the fp32 patch of the tile sit a chunk of FUSE_RC x BN new weights (transposed mirror
     // stores) and the word through which the polling lane tells the workgroup whether all slices of the tile arrived
@@ -362,6 +370,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     const int swz = (l15 >> 1) & 7;
     // AB: `ablk` = the block buffer (0 / 1) of the tile pair in work; tile `buf` (= its parity) is half `buf` of the block's k
     int ablk = 0;
+    const bool bsh = BSH && g.bshare != 0;   // (wave-uniform; the stage arguments below are compile-time constants at every call)
     auto frag_a = [&](int buf, int ks, afrag (&f)[TM], int blk_step = 0) __attribute__((always_inline)) {
         if constexpr (AB) {   // tile `buf` of the block, lane group `slot`: chunk 4 buf + slot of the 128-byte row (k-permuted plane)
             if (ks == 0) {
@@ -370,13 +379,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
             }
         } else {
-            const unsigned char* c = smem + buf * STAGE + (wm * WM + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
+            const unsigned char* c = smem + (bsh ? buf * A_BYTES : buf * STAGE) + (wm * WM + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
         }
     };
     auto frag_b = [&](int buf, int ks, int p, u32x4 (&f)[TN]) __attribute__((always_inline)) {
-        const unsigned char* c = smem + buf * STAGE + B_OFF + p * B1_BYTES + (wn * WN + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
+        const unsigned char* c = smem + (bsh ? BSH_BOFF + buf * B_BYTES : buf * STAGE + B_OFF) + p * B1_BYTES + (wn * WN + l15) * ROWB +
+                                 16 * ((4 * ks + slot) ^ swz);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) f[ni] = *reinterpret_cast<const u32x4*>(c + ni * 16 * ROWB);
     };
@@ -412,8 +422,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // micro-step holds the tile's ONLY barrier (behind it the loaders have the next tile in the other LDS buffer), then
     // reads the NEXT tile's first fragments.
     // (cur = the tile's B stage; half = its half of the A block, AB only -- with two stages the two coincide)
-    auto one_tile = [&](const int cur, const int half, auto npb_tag) __attribute__((always_inline)) {
-        const int acur = AB ? half : cur, anext = AB ? (half ^ 1) : (cur + 1) % NSTG;
+    // (bcur / anext_ / bnext_ >= 0: the B stage of this tile and the A / B stages of the next one, where they are not `cur` and
+    //  `cur + 1` -- the shared-B walk)
+    auto one_tile = [&](const int cur, const int half, auto npb_tag, const int bcur_ = -1, const int anext_ = -1,
+                        const int bnext_ = -1) __attribute__((always_inline)) {
+        const int acur = AB ? half : cur, anext = anext_ >= 0 ? anext_ : AB ? (half ^ 1) : (cur + 1) % NSTG;
+        const int bcur = bcur_ >= 0 ? bcur_ : cur, bnext = bnext_ >= 0 ? bnext_ : (cur + 1) % NSTG;
         constexpr int NPB = decltype(npb_tag)::value;
         constexpr int NU = KS * NPB;
 #ifdef KURBM_STAMPS
@@ -427,10 +441,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             if constexpr (NPB == 3) {
                 // fragments are read TWO micro-steps ahead (an LDS read under load takes longer than the 8 MFMAs
                 // of one micro-step); the tile is entered with fa[0], fb[0] loaded, so u = 0 catches up
-                if (u == 0) { frag_b(cur, 0, 1, fb[1]); frag_b(cur, 0, 2, fb[2]); }
-                if (u == 1) { frag_a(acur, 1, fa[1]); frag_b(cur, 1, 0, fb[0]); }
-                if (u == 2) frag_b(cur, 1, 1, fb[1]);
-                if (u == 3) frag_b(cur, 1, 2, fb[2]);
+                if (u == 0) { frag_b(bcur, 0, 1, fb[1]); frag_b(bcur, 0, 2, fb[2]); }
+                if (u == 1) { frag_a(acur, 1, fa[1]); frag_b(bcur, 1, 0, fb[0]); }
+                if (u == 2) frag_b(bcur, 1, 1, fb[1]);
+                if (u == 3) frag_b(bcur, 1, 2, fb[2]);
 #ifndef KURBM_BARRIER_AT
 #define KURBM_BARRIER_AT 5
 #endif
@@ -447,7 +461,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #endif
                 if (u == KURBM_NEXT_READ_AT) {
                     frag_a(anext, 0, fa[0], acur);   // (AB: after the second tile of a pair comes the other block)
-                    frag_b((cur + 1) % NSTG, 0, 0, fb[0]);
+                    frag_b(bnext, 0, 0, fb[0]);
                 }
                 mfmas(fa[ks & 1], fb[u % 3]);
                 if (KURBM_BARRIER_AT == 3 && u == 3) {
@@ -468,12 +482,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             if (u + 1 < NU) {
                 const int ksn = (u + 1) / NPB, pn = (u + 1) % NPB;
                 if (pn == 0) frag_a(acur, ksn, fa[ksn & 1]);
-                frag_b(cur, ksn, pn, fb[(u + 1) & 1]);
+                frag_b(bcur, ksn, pn, fb[(u + 1) & 1]);
             } else {
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
                 frag_a(anext, 0, fa[0], acur);   // (AB: after the second tile of a pair comes the other block)
-                frag_b((cur + 1) % NSTG, 0, 0, fb[0]);
+                frag_b(bnext, 0, 0, fb[0]);
             }
             mfmas(fa[ks & 1], fb[u & 1]);
             if (AB && (u + 1) % NPB == 0) {
@@ -562,7 +576,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         // (cdna_hip_programming.md 5, "Read a staged buffer one phase AFTER the wait that retires it").
         if (nt > 0) {
             // part: bit 0 = the A tile (AB: pieces [a_lo, a_hi) of A block `ablk_`, whose k offset is r.oa), bit 1 = the B pieces
-            auto dma_part = [&](int buf, const TileRef& r, int part, int ablk_ = 0, int a_lo = 0, int a_hi = 1 << 20) __attribute__((always_inline)) {
+            auto dma_part = [&](int buf, const TileRef& r, int part, int ablk_ = 0, int a_lo = 0, int a_hi = 1 << 20, int pb_lo = 0,
+                                int pb_hi = PB) __attribute__((always_inline)) {
 #if defined(KURBM_ABLATE) && (KURBM_ABLATE & 1)
                 return;   // timing-only build: no global loads
 #endif
@@ -576,7 +591,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 typedef __attribute__((address_space(3))) void* lds_ptr;
                 const int lw = wave - NT / 64;
                 if (part & 1) {
-                    unsigned char* a = smem + (AB ? ablk_ * A_BYTES : buf * STAGE) + lw * 8 * ROWB;   // piece it * 4 + lw
+                    unsigned char* a = smem + (AB ? ablk_ * A_BYTES : bsh ? buf * A_BYTES : buf * STAGE) + lw * 8 * ROWB;   // piece it * 4 + lw
                     if (r.neg) {   // (wave-uniform)
 #pragma unroll
                         for (int it = 0; it < NA; ++it)
@@ -590,10 +605,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     }
                 }
                 if (part & 2) {
-                    unsigned char* b = smem + buf * STAGE + B_OFF + lw * 8 * ROWB;
+                    unsigned char* b = smem + (bsh ? BSH_BOFF + buf * B_BYTES : buf * STAGE + B_OFF) + lw * 8 * ROWB;
 #pragma unroll
                     for (int p = 0; p < PB; ++p) {
                         if (p >= r.npb) break;   // (wave-uniform)
+                        if (p < pb_lo || p >= pb_hi) continue;
                         const uint32_t so = r.ob + (uint32_t)p * r.bplane;
 #pragma unroll
                         for (int it = 0; it < NB1; ++it)
@@ -784,6 +800,57 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     nb = nb == 2 ? 0 : nb + 1;
                     __builtin_amdgcn_s_barrier();
                 }
+            } else if (bsh) {
+                // tile t = 3 kt + p: A piece p of k position kt into A stage t % 3 = p, the position's three B pieces into B stage
+                // kt & 1.  While tile i is multiplied, tile i + 2 is requested -- its A stage is tile i - 1's -- and with it ONE B
+                // piece of the k position at or behind it, so that every request is 10 pieces per wave: with tile (kt, 1) piece 2 of
+                // position kt + 1 (the tiles of kt - 1 that read that piece of the stage are behind their barriers), with tile
+                // (kt, 2) its piece 1, with tile (kt + 1, 0) its piece 0.  The barrier waits for everything but that request:
+                // tile i + 1 has landed.
+                Walk w = walk_at(t_begin);
+                TileRef rb = walk_ref(w);                        // (B of k position 0; its offset moves on by 128 bytes per position)
+                rb.npb = 3;
+                {
+                    const TileRef r0 = rb; walk_next(w);
+                    dma_part(0, r0, 1); dma_part(0, rb, 2);                          // tile 0: A piece 0, all of B(0)
+                    rb.ob += 128u;                                                   // -> position 1, stage 1
+                    if (nt > 1) {
+                        const TileRef r1 = walk_ref(w); walk_next(w);
+                        dma_part(1, r1, 1);                                          // tile 1: A piece 1
+                        if (nt > 3) dma_part(1, rb, 2, 0, 0, 0, 2, 3);               // ... and piece 2 of B(1)
+                    }
+                }
+                if (nt > 3) __builtin_amdgcn_s_waitcnt(vm(NA + NB1)); else if (nt > 1) __builtin_amdgcn_s_waitcnt(vm(NA)); else __builtin_amdgcn_s_waitcnt(VM0);
+                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
+                __builtin_amdgcn_s_barrier();
+                int p2 = 2, bst = 1;                             // tile i + 2: its piece (= A stage); the B stage being filled
+                for (int i = 0; i < nt; ++i) {
+                    KURBM_LSTAMP(0);
+                    if (i + 2 < nt) {
+                        const TileRef r = walk_ref(w); walk_next(w);
+                        dma_part(p2, r, 1);
+                        // B piece (3 - p2) % 3 of the position being filled, if there is one: i + 2 + (its distance to that position's first tile) < nt
+                        const int first = i + 2 + ((3 - p2) % 3);
+                        KURBM_LSTAMP(1);
+                        if (first < nt) {
+                            if (p2 == 2) dma_part(bst, rb, 2, 0, 0, 0, 1, 2);
+                            else if (p2 == 0) dma_part(bst, rb, 2, 0, 0, 0, 0, 1);
+                            else dma_part(bst, rb, 2, 0, 0, 0, 2, 3);
+                            __builtin_amdgcn_s_waitcnt(vm(NA + NB1));
+                        } else {
+                            __builtin_amdgcn_s_waitcnt(vm(NA));
+                        }
+                        if (p2 == 0) { rb.ob += 128u; bst ^= 1; }   // (position complete: on to the next one, the other stage)
+                    } else {
+                        KURBM_LSTAMP(1);
+                        __builtin_amdgcn_s_waitcnt(VM0);
+                    }
+                    if (++p2 == 3) p2 = 0;
+                    KURBM_LSTAMP(2);
+                    __builtin_amdgcn_s_barrier();
+                    KURBM_LSTAMP(3);
+                }
+                KURBM_LSTAMP_OUT();
             } else {
             // both stages are free at the start: tiles 0 and 1 are requested back to back, and the first barrier waits for
             // tile 0's pieces only (a counted vmcnt leaves tile 1's in flight)
@@ -1073,7 +1140,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 }
                 if (i < nt) one_tile(0, 0, std::integral_constant<int, PB>{});
             } else {
-                if (F8 && g.walk3) {
+                if (bsh) {
+                    // k position kt = tiles (A piece 0 x 3 B pieces), (piece 1 x 2), (piece 2 x 1): A stage = the piece, B stage =
+                    // kt & 1 for all three -- six tiles per trip
+                    typedef std::integral_constant<int, 3> N3; typedef std::integral_constant<int, 2> N2; typedef std::integral_constant<int, 1> N1;
+                    for (; i + 5 < nt; i += 6) {
+                        one_tile(0, 0, N3{}, 0, 1, 0); one_tile(1, 0, N2{}, 0, 2, 0); one_tile(2, 0, N1{}, 0, 0, 1);
+                        one_tile(0, 0, N3{}, 1, 1, 1); one_tile(1, 0, N2{}, 1, 2, 1); one_tile(2, 0, N1{}, 1, 0, 0);
+                    }
+                    if (i < nt) { one_tile(0, 0, N3{}, 0, 1, 0); one_tile(1, 0, N2{}, 0, 2, 0); one_tile(2, 0, N1{}, 0, 0, 1); }
+                } else if (F8 && g.walk3) {
                     // whole units of fp8, 3-piece, 3-piece; the stages alternate: six tiles per trip
                     for (; i + 5 < nt; i += 6) {
                         f8_tile(0);
@@ -1742,6 +1818,9 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
                 }
         }
     }
+    // shared B staging: a three-piece A operand against three-piece weights, (piece p) x (pieces 0 .. 2 - p), one k slice
+    g.bshare = (epi == EPI_HALFSTEP && g.pb_max == 3 && !g.a_bytes && g.nseg == 3 && g.nsplit == 1 && g.seg_fastest &&
+                (g.seg_codes & 0x7FFFull) == ((0ull | (3ull << 2)) | ((1ull | (2ull << 2)) << 5) | ((2ull | (1ull << 2)) << 10))) ? 1 : 0;
     g.walk3 = (epi == EPI_SLAB && g.pb_max == 3 && g.f8pos && g.nseg == 2 && ((g.seg_codes >> 7) & 3u) == 3u &&
                g.kt_per_split % 3 == 0 && g.kt_total % 3 == 0) ? 1 : 0;
     {   // the block mapping's divisors as multiply-high constants: exact while dividend x divisor < 2^32 (every grid of the
