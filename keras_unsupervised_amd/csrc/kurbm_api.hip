@@ -1051,6 +1051,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.pb_max = pieces;
         g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
         if (f8pos) { g.f8pos = 1; g.inv_nseg = inv_of(2 * g.nseg - 1); }   // (tiles per 128-deep unit)
+        g.bshare_ok = ctx->knob[KN_X3_BSHARE];
         g.m_fastest = ctx->knob[KN_X3_STATS_MFAST];
         g.cfg = pl.cfg;
         g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);

@@ -167,7 +167,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     constexpr bool BSH = !AB && PB == 3 && EPI == EPI_HALFSTEP;
     constexpr int BSH_BYTES = 3 * A_BYTES + 2 * B_BYTES, BSH_BOFF = 3 * A_BYTES;
     constexpr int SMEM_BYTES0 = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
-    constexpr int SMEM_BYTES = (BSH && BSH_BYTES > SMEM_BYTES0) ? BSH_BYTES : SMEM_BYTES0;
+    // BSH2 (g.bshare2; the statistics GEMM of real-valued data): the same ring of three A stages; a B stage holds the k position's
+    // positive piece and its three negative pieces (four piece slots)
+    constexpr int BSH2_BYTES = 3 * A_BYTES + 2 * 4 * B1_BYTES;
+    constexpr bool BSH2 = !AB && PB == 3 && EPI == EPI_SLAB && BSH2_BYTES <= 160 * 1024;
+    constexpr int SMEM_BYTES1 = (BSH && BSH_BYTES > SMEM_BYTES0) ? BSH_BYTES : SMEM_BYTES0;
+    constexpr int SMEM_BYTES = (BSH2 && BSH2_BYTES > SMEM_BYTES1) ? BSH2_BYTES : SMEM_BYTES1;
     // the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
     // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
     // (none beside the BSH layout: 144 of the 160 KB)
@@ -370,7 +375,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     const int swz = (l15 >> 1) & 7;
     // AB: `ablk` = the block buffer (0 / 1) of the tile pair in work; tile `buf` (= its parity) is half `buf` of the block's k
     int ablk = 0;
-    const bool bsh = BSH && g.bshare != 0;   // (wave-uniform; the stage arguments below are compile-time constants at every call)
+    const bool bsh2 = BSH2 && g.bshare2 != 0;
+    const bool bsh = (BSH && g.bshare != 0) || bsh2;   // (wave-uniform; BSH: the stage arguments are compile-time constants at every call)
+    const int bsh_bstride = bsh2 ? 4 * B1_BYTES : B_BYTES;   // (a B stage: the three pieces; BSH2: four piece slots)
     auto frag_a = [&](int buf, int ks, afrag (&f)[TM], int blk_step = 0) __attribute__((always_inline)) {
         if constexpr (AB) {   // tile `buf` of the block, lane group `slot`: chunk 4 buf + slot of the 128-byte row (k-permuted plane)
             if (ks == 0) {
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         }
     };
     auto frag_b = [&](int buf, int ks, int p, u32x4 (&f)[TN]) __attribute__((always_inline)) {
-        const unsigned char* c = smem + (bsh ? BSH_BOFF + buf * B_BYTES : buf * STAGE + B_OFF) + p * B1_BYTES + (wn * WN + l15) * ROWB +
+        const unsigned char* c = smem + (bsh ? BSH_BOFF + buf * bsh_bstride : buf * STAGE + B_OFF) + p * B1_BYTES + (wn * WN + l15) * ROWB +
                                  16 * ((4 * ks + slot) ^ swz);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) f[ni] = *reinterpret_cast<const u32x4*>(c + ni * 16 * ROWB);
@@ -424,8 +431,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // (cur = the tile's B stage; half = its half of the A block, AB only -- with two stages the two coincide)
     // (bcur / anext_ / bnext_ >= 0: the B stage of this tile and the A / B stages of the next one, where they are not `cur` and
     //  `cur + 1` -- the shared-B walk)
+    //  pb0 / pb0n: the piece slot of this tile's / the next tile's piece 0 in its B stage (BSH2))
     auto one_tile = [&](const int cur, const int half, auto npb_tag, const int bcur_ = -1, const int anext_ = -1,
-                        const int bnext_ = -1) __attribute__((always_inline)) {
+                        const int bnext_ = -1, const int pb0 = 0, const int pb0n = 0) __attribute__((always_inline)) {
         const int acur = AB ? half : cur, anext = anext_ >= 0 ? anext_ : AB ? (half ^ 1) : (cur + 1) % NSTG;
         const int bcur = bcur_ >= 0 ? bcur_ : cur, bnext = bnext_ >= 0 ? bnext_ : (cur + 1) % NSTG;
         constexpr int NPB = decltype(npb_tag)::value;
@@ -441,10 +449,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             if constexpr (NPB == 3) {
                 // fragments are read TWO micro-steps ahead (an LDS read under load takes longer than the 8 MFMAs
                 // of one micro-step); the tile is entered with fa[0], fb[0] loaded, so u = 0 catches up
-                if (u == 0) { frag_b(bcur, 0, 1, fb[1]); frag_b(bcur, 0, 2, fb[2]); }
-                if (u == 1) { frag_a(acur, 1, fa[1]); frag_b(bcur, 1, 0, fb[0]); }
-                if (u == 2) frag_b(bcur, 1, 1, fb[1]);
-                if (u == 3) frag_b(bcur, 1, 2, fb[2]);
+                if (u == 0) { frag_b(bcur, 0, pb0 + 1, fb[1]); frag_b(bcur, 0, pb0 + 2, fb[2]); }
+                if (u == 1) { frag_a(acur, 1, fa[1]); frag_b(bcur, 1, pb0, fb[0]); }
+                if (u == 2) frag_b(bcur, 1, pb0 + 1, fb[1]);
+                if (u == 3) frag_b(bcur, 1, pb0 + 2, fb[2]);
 #ifndef KURBM_BARRIER_AT
 #define KURBM_BARRIER_AT 5
 #endif
@@ -461,7 +469,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #endif
                 if (u == KURBM_NEXT_READ_AT) {
                     frag_a(anext, 0, fa[0], acur);   // (AB: after the second tile of a pair comes the other block)
-                    frag_b(bnext, 0, 0, fb[0]);
+                    frag_b(bnext, 0, pb0n, fb[0]);
                 }
                 mfmas(fa[ks & 1], fb[u % 3]);
                 if (KURBM_BARRIER_AT == 3 && u == 3) {
@@ -482,12 +490,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             if (u + 1 < NU) {
                 const int ksn = (u + 1) / NPB, pn = (u + 1) % NPB;
                 if (pn == 0) frag_a(acur, ksn, fa[ksn & 1]);
-                frag_b(bcur, ksn, pn, fb[(u + 1) & 1]);
+                frag_b(bcur, ksn, pb0 + pn, fb[(u + 1) & 1]);
             } else {
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
                 frag_a(anext, 0, fa[0], acur);   // (AB: after the second tile of a pair comes the other block)
-                frag_b(bnext, 0, 0, fb[0]);
+                frag_b(bnext, 0, pb0n, fb[0]);
             }
             mfmas(fa[ks & 1], fb[u & 1]);
             if (AB && (u + 1) % NPB == 0) {
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         if (nt > 0) {
             // part: bit 0 = the A tile (AB: pieces [a_lo, a_hi) of A block `ablk_`, whose k offset is r.oa), bit 1 = the B pieces
             auto dma_part = [&](int buf, const TileRef& r, int part, int ablk_ = 0, int a_lo = 0, int a_hi = 1 << 20, int pb_lo = 0,
-                                int pb_hi = PB) __attribute__((always_inline)) {
+                                int pb_hi = PB, int pb_dst = 0) __attribute__((always_inline)) {
 #if defined(KURBM_ABLATE) && (KURBM_ABLATE & 1)
                 return;   // timing-only build: no global loads
 #endif
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     }
                 }
                 if (part & 2) {
-                    unsigned char* b = smem + (bsh ? BSH_BOFF + buf * B_BYTES : buf * STAGE + B_OFF) + lw * 8 * ROWB;
+                    unsigned char* b = smem + (bsh ? BSH_BOFF + buf * bsh_bstride + pb_dst * B1_BYTES : buf * STAGE + B_OFF) + lw * 8 * ROWB;
 #pragma unroll
                     for (int p = 0; p < PB; ++p) {
                         if (p >= r.npb) break;   // (wave-uniform)
@@ -800,6 +808,49 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     nb = nb == 2 ? 0 : nb + 1;
                     __builtin_amdgcn_s_barrier();
                 }
+            } else if (bsh2) {
+                // statistics of real-valued data.  Tile j of the slice: A tile into A stage j % 3; the B pieces of a k position --
+                // the positive piece into slot 0, the three negative ones into slots 1-3 of B stage (position & 1) -- are requested
+                // with the position's first tile.  While tile i is multiplied tile i + 2 is requested (its A stage is tile i - 1's;
+                // the B stage was last read by the position before last) and the barrier waits for everything but that request.
+                const int np = g.bsh_np;
+                Walk w = walk_at(t_begin);
+                const int kt0 = w.b;
+                auto issue = [&](int ast) __attribute__((always_inline)) {   // the tile at `w`; returns 1 if the position's B went with it
+                    const Walk c = w;
+                    const TileRef r = walk_ref(c);
+                    walk_next(w);
+                    dma_part(ast, r, 1);
+                    if (c.a != 0) return 0;
+                    const int st = (c.b - kt0) & 1;
+                    dma_part(st, r, 2, 0, 0, 0, 0, 1, 0);                       // (segment 0 is a positive one: its one B piece)
+                    Walk cn = c; cn.a = np;
+                    const TileRef rn = walk_ref(cn);
+                    dma_part(st, rn, 2, 0, 0, 0, 0, 3, 1);                      // the negative pieces
+                    return 1;
+                };
+                issue(0);
+                if (nt > 1) issue(1);
+                if (nt > 1) __builtin_amdgcn_s_waitcnt(vm(NA)); else __builtin_amdgcn_s_waitcnt(VM0);
+                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
+                __builtin_amdgcn_s_barrier();
+                int a2 = 2;
+                for (int i = 0; i < nt; ++i) {
+                    KURBM_LSTAMP(0);
+                    if (i + 2 < nt) {
+                        const int withb = issue(a2);
+                        KURBM_LSTAMP(1);
+                        if (withb) __builtin_amdgcn_s_waitcnt(vm(NA + 4 * NB1)); else __builtin_amdgcn_s_waitcnt(vm(NA));
+                    } else {
+                        KURBM_LSTAMP(1);
+                        __builtin_amdgcn_s_waitcnt(VM0);
+                    }
+                    a2 = (a2 == 2) ? 0 : a2 + 1;
+                    KURBM_LSTAMP(2);
+                    __builtin_amdgcn_s_barrier();
+                    KURBM_LSTAMP(3);
+                }
+                KURBM_LSTAMP_OUT();
             } else if (bsh) {
                 // tile t = 3 kt + p: A piece p of k position kt into A stage t % 3 = p, the position's three B pieces into B stage
                 // kt & 1.  While tile i is multiplied, tile i + 2 is requested -- its A stage is tile i - 1's -- and with it ONE B
@@ -1140,7 +1191,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 }
                 if (i < nt) one_tile(0, 0, std::integral_constant<int, PB>{});
             } else {
-                if (bsh) {
+                if (bsh2) {
+                    // (see the loaders) run-time stages; a tile's piece count comes from the segment table
+                    const int np = g.bsh_np, ns = g.nseg;
+                    int ast = 0, bst = 0, seg = 0;
+                    for (; i < nt; ++i) {
+                        const int segn = (seg + 1 == ns) ? 0 : seg + 1;
+                        const int astn = (ast == 2) ? 0 : ast + 1, bstn = (segn == 0) ? (bst ^ 1) : bst;
+                        const int pb0 = (seg < np) ? 0 : 1, pb0n = (segn < np) ? 0 : 1;
+                        const int npb = (int)((__builtin_amdgcn_readlane(t_code, seg) >> 2) & 3u);
+                        if (npb == 3) one_tile(ast, 0, std::integral_constant<int, 3>{}, bst, astn, bstn, pb0, pb0n);
+                        else if (npb == 2) one_tile(ast, 0, std::integral_constant<int, 2>{}, bst, astn, bstn, pb0, pb0n);
+                        else one_tile(ast, 0, std::integral_constant<int, 1>{}, bst, astn, bstn, pb0, pb0n);
+                        seg = segn; ast = astn; bst = bstn;
+                    }
+                } else if (bsh) {
                     // k position kt = tiles (A piece 0 x 3 B pieces), (piece 1 x 2), (piece 2 x 1): A stage = the piece, B stage =
                     // kt & 1 for all three -- six tiles per trip
                     typedef std::integral_constant<int, 3> N3; typedef std::integral_constant<int, 2> N2; typedef std::integral_constant<int, 1> N1;
@@ -1821,6 +1886,20 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     // shared B staging: a three-piece A operand against three-piece weights, (piece p) x (pieces 0 .. 2 - p), one k slice
     g.bshare = (epi == EPI_HALFSTEP && g.pb_max == 3 && !g.a_bytes && g.nseg == 3 && g.nsplit == 1 && g.seg_fastest &&
                 (g.seg_codes & 0x7FFFull) == ((0ull | (3ull << 2)) | ((1ull | (2ull << 2)) << 5) | ((2ull | (1ull << 2)) << 10))) ? 1 : 0;
+    // the statistics of real-valued data: positive segments (set 0, one B piece each) in front of the negative ones (set 1, the
+    // first with three B pieces), segment-fastest, whole k positions per slice, no fp8 tiles
+    g.bshare2 = 0; g.bsh_np = 0;
+    if (epi == EPI_SLAB && g.pb_max == 3 && !g.a_bytes && !g.f8pos && g.seg_fastest && g.cfg == 2 && g.nseg >= 2 && g.nseg <= 12 &&
+        g.kt_per_split % g.nseg == 0 && g.kt_total % g.nseg == 0 && g.bshare_ok) {
+        int np = 0, ok = 1;
+        for (int sg = 0; sg < g.nseg; ++sg) {
+            const unsigned code = (unsigned)(g.seg_codes >> (5 * sg)) & 31u;
+            const int neg = (code >> 4) & 1, npb = (code >> 2) & 3;
+            if (!neg) { if (np != sg || npb != 1) ok = 0; else ++np; }            // positive ones first, one piece each
+            else if (sg == np && npb != 3) ok = 0;                                // the first negative one brings all three pieces
+        }
+        if (ok && np >= 1 && np < g.nseg) { g.bshare2 = 1; g.bsh_np = np; }
+    }
     g.walk3 = (epi == EPI_SLAB && g.pb_max == 3 && g.f8pos && g.nseg == 2 && ((g.seg_codes >> 7) & 3u) == 3u &&
                g.kt_per_split % 3 == 0 && g.kt_total % 3 == 0) ? 1 : 0;
     {   // the block mapping's divisors as multiply-high constants: exact while dividend x divisor < 2^32 (every grid of the
