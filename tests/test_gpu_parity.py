@@ -1284,6 +1284,30 @@ def test_fused_slab_reduction_is_bit_identical(gpu_device, ctx_option, cfg):
     assert np.all(np.isfinite(got[1][0])) and not np.array_equal(got[1][0], W0[0])
 
 
+@pytest.mark.parametrize("shape", [(4096, 784, 1024), (1024, 1000, 300), (512, 260, 1024), (300, 784, 100)])
+def test_shared_b_half_step_equals_segment_by_segment(gpu_device, ctx_option, shape):
+    """A real-valued A operand on the x3 path: the three tiles of a k position sharing one staging of its B pieces
+    (KURBM_X3_BSHARE=1, the default: segments walked k position by k position) against the segments one after the other
+    (=0).  The same piece pairs, multiplied exactly, summed in another order: the probabilities agree to fp32 rounding, the
+    uniforms are the same numbers, and both sit within the fp32 tolerance of the oracle.  rbm.py:214."""
+    B, nv, nh = shape
+    W0 = synthetic_params(nv, nh, seed=2500 + B)
+    V = synthetic_real(B, nv, seed=2501 + B)
+    got = {}
+    for share in (1, 0):
+        ctx_option("KURBM_X3_BSHARE", share, 1)
+        e = _engine(*W0, gpu_device)
+        out = e.half_step_bf16("vh", _dm(V, gpu_device), B, 0, 1, 5, 2, 3, pieces=3)
+        torch.cuda.synchronize()
+        got[share] = {k: out[k].to_numpy() for k in ("prob", "u", "sample")}
+    assert np.array_equal(got[1]["u"], got[0]["u"])
+    assert np.max(np.abs(got[1]["prob"] - got[0]["prob"])) <= 2e-6
+    flips = got[1]["sample"] != got[0]["sample"]
+    assert np.all(np.abs(got[1]["u"] - got[1]["prob"])[flips] < 1e-5)
+    ref = O.sigmoid(V.astype(np.float64) @ W0[0].astype(np.float64) + W0[1].astype(np.float64))
+    assert np.max(np.abs(got[1]["prob"] - ref)) <= 1e-5
+
+
 @pytest.mark.parametrize("cfg", [dict(B=4096, nv=784, nh=1024), dict(B=1024, nv=784, nh=256, xcd2d=0), dict(B=512, nv=300, nh=200),
                                  dict(B=1024, nv=1024, nh=1024, compute="bf16"), dict(B=2048, nv=1024, nh=784, real=True, xcd2d=0)])
 def test_block_mapping_by_division_is_the_same_mapping(gpu_device, ctx_option, cfg):
