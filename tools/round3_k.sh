@@ -5,6 +5,8 @@ C=$R/keras_unsupervised_amd/csrc
 V=${VARIANT:-libkurbm_var.so}
 timeout -k 10 900 python -m pytest tests -m gpu -q -x > $O/tests.txt 2>&1 || { tail -30 $O/tests.txt; exit 1; }
 tail -1 $O/tests.txt
+# (TESTVAR=1: the parity tests of the x3 path on the VARIANT too)
+[ -n "$TESTVAR" ] && { KURBM_LIB=$C/$V timeout -k 10 900 python -m pytest tests -m gpu -q -x -k "x3 or config2 or score or stats or fused" > $O/tests_variant.txt 2>&1 || { tail -30 $O/tests_variant.txt; exit 1; }; tail -1 $O/tests_variant.txt; }
 for rep in 1 2 3; do
   for lib in libkurbm.so $V; do
     echo "== $lib" >> $O/ab.txt
