@@ -39,13 +39,49 @@ import time
 # (RCCL / device-memory sharing across the processes of a node needs dmabuf IPC on this stack; the GPU boxes export it already)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip paths.* beyond x3 / fp32 (real-valued data, Gaussian mode): they launch the SAME kernels with more "
+                         "segments, which would blur a rocprofv3 --stats average of the config-2 launches (tools/profile_round.sh)")
+    ap.add_argument("--compute", choices=("x3", "fp32"), default=os.environ.get("BENCH_COMPUTE", "x3"))
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start one rank per GPU as CHILD processes
+    (python -m torch.distributed.run ... bench.py ...), forward their output (rank 0 prints the JSON line) and exit with the
+    launcher's code.  This runs before torch is imported: the parent never touches a GPU, and nothing that has is re-executed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: WORLD_SIZE unset, --gpus %d: launching %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=dict(os.environ))
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _args = parse_args()
+    if _args.gpus > 1:
+        sys.exit(self_launch(_args))
+
+import numpy as np
+import torch
+import torch.distributed as dist
 
 N_VIS, N_HID, BATCH = 784, 1024, 4096
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: 256 CU x 256 flop/clk x 2.4 GHz
@@ -76,23 +112,18 @@ def event_time_ms(fn, iters, warm=3):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-variants", action="store_true",
-                    help="skip paths.* beyond x3 / fp32 (real-valued data, Gaussian mode): they launch the SAME kernels with more "
-                         "segments, which would blur a rocprofv3 --stats average of the config-2 launches (tools/profile_round.sh)")
-    ap.add_argument("--compute", choices=("x3", "fp32"), default=os.environ.get("BENCH_COMPUTE", "x3"))
-    args = ap.parse_args()
+    args = parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
-                 "--master-port P bench.py --gpus %d ...  (WORLD_SIZE is %d)" % (args.gpus, args.gpus, world))
+        # (WORLD_SIZE unset and --gpus N > 1 never gets here: bench.py then launches its own ranks, see self_launch)
+        sys.exit("WORLD_SIZE is %d but --gpus is %d: start bench.py without a launcher (it starts its own ranks), or with "
+                 "python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py "
+                 "--gpus %d ..." % (world, args.gpus, args.gpus, args.gpus))
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("rank %d: local rank %d has no GPU (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -161,6 +192,57 @@ def main():
     steady = [timed_block(args.steps) for _ in range(repeats)]
     assert bool(torch.isfinite(eng.W.t).all().item()), "weights diverged"
     fence()          # every rank is past its last data-parallel step; from here on only rank 0 touches its GPU
+
+    # ---- the honest variants, under the SAME block protocol as `value` (single GPU, x3) -------------------------------------
+    # value_convert_per_step: no resident planes -- every step converts its own 4096 rows, as the FIRST epoch of a fit() does
+    #   for every window (the reference's example conf is `epochs: 1`: rbm_softmax_mnist_conf.json:14);
+    # value_reference_default: what `RBM(hps, n).fit(V)` is in the reference -- the constructor's default Gaussian-visible mode
+    #   (rbm.py:22) on grey-level data (rbm_softmax_mnist.py:103) with the default verbose = 1, i.e. the update AND the score pass
+    #   (rbm.py:225-234) every step; planes resident, the score left on the device as fit() leaves it.
+    variants = {}
+    if world == 1 and args.compute == "x3" and not args.no_variants:
+        from keras_unsupervised_amd.ebm.engine import CHAIN_SCORE
+
+        def protocol(step_fn):
+            c = [0]
+            def block(k):
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    step_fn(c[0])
+                    c[0] += 1
+                fence()
+                return time.perf_counter() - t0
+            for _ in range(args.warmup):
+                step_fn(c[0])
+                c[0] += 1
+            bl = [block(args.steps) for _ in range(repeats)]
+            med = statistics.median(bl)
+            return {"value": args.steps / med, "ms_per_step": med / args.steps * 1e3, "value_first_block": args.steps / bl[0],
+                    "block_ms": [b * 1e3 for b in bl]}
+        Wkeep0 = eng.get_weights()
+        variants["value_convert_per_step"] = protocol(
+            lambda i: eng.cd_step(V, BATCH, (i % n_batches) * BATCH, lr, seed, i, compute="x3", planes=None))
+        ug = eng.philox_uniform(n_batches * BATCH, N_VIS, 99, 0x7005, 0)
+        Vg16 = DeviceMatrix((torch.floor(ug.t * 256.0) / 255.0).contiguous(), n_batches * BATCH, N_VIS, ug.ld)
+        del ug
+        plg16 = eng.make_planes(Vg16, [(i * BATCH, BATCH) for i in range(n_batches)], MODE_VISIBLE_GAUSSIAN)
+
+        def ref_default(i, score=True, mode=MODE_VISIBLE_GAUSSIAN):
+            lo = (i % n_batches) * BATCH
+            eng.cd_step(Vg16, BATCH, lo, lr, seed, i, mode=mode, compute="x3", planes=plg16)
+            if score:
+                eng.score_x3(Vg16, BATCH, lo, seed, i, mode, CHAIN_SCORE, planes=plg16)
+        variants["value_reference_default"] = protocol(ref_default)
+        variants["value_reference_default_quiet"] = protocol(lambda i: ref_default(i, score=False))
+        variants["value_grey_level_bernoulli"] = protocol(lambda i: ref_default(i, score=False, mode=0))
+        variants["note"] = ("same block protocol as `value` (W = %d warm-up steps, %d blocks of %d steps, median): value_convert_per_step = 0/1 data, "
+                            "no resident planes (the epochs: 1 case); value_reference_default = Gaussian-visible mode (rbm.py:22) on grey-level "
+                            "data with the score pass of fit(verbose=1) (rbm.py:225-234) in every step; _quiet = the same without the score; "
+                            "value_grey_level_bernoulli = Bernoulli mode on the same data, no score" % (args.warmup, repeats, args.steps))
+        eng.set_weights(*Wkeep0)
+        del Vg16, plg16
+        fence()
 
     out = None
     if rank == 0:
@@ -258,6 +340,9 @@ def main():
             roofline = {"bound": "mfma", "kernel": dom, "achieved": kern_x3[dom]["executed_tflops"],
                         "peak": kern_x3[dom]["executed_tflops"] / kern_x3[dom]["frac_of_mfma_roof"], "unit": "TFLOP/s",
                         "frac": kern_x3[dom]["frac_of_mfma_roof"],
+                        "frac_algorithmic": kern_x3[dom]["algorithmic_tflops"] / PEAK_BF16_MFMA_TFLOPS,
+                        "frac_algorithmic_note": "SURVEY 8(d)'s algorithmic flop of the launch (statistics 4 B V H, a half step 2 B V H) over its "
+                                                 "duration, against the dense bf16 MFMA peak (the unit that executes it)",
                         "note": "EXECUTED MFMA flop of the launch (3 GEMM units per half step: the three bf16 pieces of W; statistics: "
                                 "v_pos^T h_pos, 0/1 x 0/1, one unit on the fp8 matrix cores + three bf16 units for v_neg^T h_neg; one unit = "
                                 "2 B V H) over the launch duration (HIP events, this run); peak = that flop over the time its MFMAs "
@@ -291,6 +376,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "value_first_block": rate(blocks[0]), "value_steady": rate(statistics.median(steady)),
             "rccl_ranks": rccl_ranks,
+            "value_convert_per_step": variants.get("value_convert_per_step", {}).get("value"),
+            "value_reference_default": variants.get("value_reference_default", {}).get("value"),
+            "variants": variants or None,
             "config": {"workload": "rbm_784x1024_cd1_batch4096_fp32 (BASELINE.json configs[1]%s)" % ("" if world == 1 else "; configs[2] shape: 4096 rows per GPU"),
                        "n_vis": N_VIS, "n_hid": N_HID, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "cd_k": 1, "update_mode": "fused", "lr": "1e-3/4096", "parallelism": "dp%d" % world,

@@ -120,7 +120,9 @@ int kurbm_ctx_set_option(kurbm_ctx* ctx, const char* name, int value);
  * others never do) and cleared.  Bit 0: a workgroup of the statistics GEMM of kurbm_cd_step_x3 / _bf16 -- which reduces
  * its own split-K slabs when its whole grid is resident, one workgroup per CU -- gave up waiting for the other k-slices of
  * its tile (0.2 s), i.e. the grid was NOT resident (a CU mask, a device shared with a kernel that never ends): that
- * step's update of W is incomplete.  0 in every run this build has seen; set KURBM_X3_FUSED=0 where it is not. */
+ * step's update of W is incomplete.  That in-launch reduction is OFF by default (knob KURBM_X3_FUSED, default 0: the separate
+ * slab-reduce launch runs, which cannot time out); with KURBM_X3_FUSED=1 the bit has been 0 in every run this build has seen,
+ * and the host classes read it at the end of every fit() / epoch call and raise before training goes on. */
 int kurbm_ctx_status(kurbm_ctx* ctx, int* bits);
 
 /* ---- RNG test hook: out[r, c] = u(row0 + r, c) under the contract above -------- */
@@ -377,11 +379,13 @@ int kurbm_allreduce_sum_f32(kurbm_comm* comm, float* buf, size_t n, kurbm_stream
  * opts->apply = 1 -- W, b_h, b_v += lr * (summed delta) and the weight-piece mirror rewritten, in one launch, once the
  * last all-reduce has landed.  opts->delta_out (packed, required) holds the SUMMED statistics afterwards.  rows = 0
  * is legal (a rank that owns no rows of a remainder batch contributes zeros; v_batch is not read).  n_chunks <= 0:
- * the library picks by the size of the exchange -- ONE range, all-reduced on `stream` itself, up to 8 MB (on MI355X /
- * ROCm 7 the hand-off between two streams costs more than a 3.2 MB all-reduce can hide), ranges of ~16 MB above (the
- * 67 MB of a 4096 x 4096 RBM travel as four) -- DESIGN.md section 5.  With several ranges each one is APPLIED (its rows of
- * W, its part of the mirror) on the comm stream as soon as its all-reduce has landed, under the statistics GEMM of the
- * next.  Every rank must pass the same n_chunks.  All work is ordered on `stream` from the caller's point of view.
+ * ONE range, all-reduced on `stream` itself, whatever the size of the exchange (on MI355X / ROCm 7 the hand-off between two
+ * streams costs more than a 3.2 MB all-reduce can hide, and the several-range schedule has not run at a world size above 1
+ * yet) unless the context knob KURBM_DP_CHUNKS names a count -- DESIGN.md section 5.  Several ranges are an OPT-IN
+ * (n_chunks > 1 or KURBM_DP_CHUNKS > 1): each one is then APPLIED (its rows of W, its part of the mirror) on the comm stream
+ * as soon as its all-reduce has landed, under the statistics GEMM of the next; a HIP failure in that loop still joins the
+ * comm stream back to `stream` before it is reported.  Every rank must pass the same n_chunks.  All work is ordered on
+ * `stream` from the caller's point of view.
  * Every argument is checked before the first collective is enqueued, so a refused call has not joined an all-reduce
  * (the checks depend on arguments all ranks share; `rows` may differ).
  */

@@ -1350,17 +1350,15 @@ static int apply_delta_rows(kurbm_ctx* ctx, const kurbm_params* p, void* mirror,
     return KURBM_OK;
 }
 
-// Row ranges of dW for an exchange of `bytes` bytes.  ONE range up to 12 MiB: on MI355X / ROCm 7 a hand-off between two HIP
-// streams costs 12-16 us per event wait and a statistics GEMM cut in two ~13 us (tools/dp_times.py) -- ~49 us before the second
-// range's all-reduce can start, more than the half of a 3.2 MB exchange it could hide (ring wire time 37 us at 8 ranks).  Above
-// that, ranges of ~16 MiB (ring wire time ~190 us each, the hand-offs ~50 us in all): the 67 MB of a 4096 x 4096 RBM travel
-// as four, and all but the last range's exchange and apply run under the statistics GEMM of the next.
-static int auto_chunks(size_t bytes) {
-    if (bytes <= (12u << 20)) return 1;
-    int n = (int)((bytes + (8u << 20)) / (16u << 20));
-    if (n < 2) n = 2;
-    return n > kurbm_comm::MAX_CHUNKS ? kurbm_comm::MAX_CHUNKS : n;
-}
+// Row ranges of dW in the data-parallel step.  The AUTOMATIC choice (n_chunks <= 0, knob KURBM_DP_CHUNKS unset) is ONE range,
+// all-reduced on the caller's stream, whatever the size of the exchange: on MI355X / ROCm 7 a hand-off between two HIP streams
+// costs 12-16 us per event wait and a statistics GEMM cut in two ~13 us (tools/dp_times.py) -- ~49 us before a second range's
+// all-reduce can start, more than the half of a 3.2 MB exchange it could hide -- and the several-range schedule (range i
+// all-reduced and applied on the comm stream under the statistics GEMM of range i + 1) has never run at a world size above 1
+// (tests/test_two_gpus.py is skipped on every box this build has seen).  It stays in the tree as an OPT-IN: the caller's
+// n_chunks > 1, or KURBM_DP_CHUNKS > 1 (every rank must pass the same value), e.g. 4 ranges of ~16 MiB for the 67 MB of a
+// 4096 x 4096 RBM once tests/test_two_gpus.py has passed on a real node.
+static int auto_chunks(size_t /*bytes*/) { return 1; }
 
 static int cd_step_dp_any(kurbm_ctx* ctx, kurbm_comm* comm, int pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                           const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks,
@@ -1395,7 +1393,14 @@ static int cd_step_dp_any(kurbm_ctx* ctx, kurbm_comm* comm, int pieces, const ku
     else if (nc > 1)
         if (int e = cd_step_any(ctx, pieces, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream, 8))
             return e;
-    for (int c = 0; c < nc; ++c) {
+    // Once the first collective of a several-range step is enqueued, this rank must finish the sequence as far as the other
+    // ranks can see it: a failure inside the loop (a HIP error of a launch or an event call) still records ev_done on the comm
+    // stream and makes the caller's stream wait for it before the error is returned -- the comm stream never stays ahead of
+    // the caller's, and the collectives already enqueued complete against the peers' matching ones.  (Argument errors cannot
+    // occur here: check_cd_args ran before anything was enqueued.)
+    int err = KURBM_OK;
+    bool on_comm = false;
+    auto range = [&](int c) -> int {
         if (rows > 0) {
             const int e = (nc == 1)
                 ? cd_step_any(ctx, pieces, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream)
@@ -1404,22 +1409,26 @@ static int cd_step_dp_any(kurbm_ctx* ctx, kurbm_comm* comm, int pieces, const ku
             if (e) return e;
         }
         const size_t lo = (size_t)bound[c] * p->n_hid, hi = (c + 1 == nc) ? ntot : (size_t)bound[c + 1] * p->n_hid;
-        if (nc == 1) {   // nothing to overlap with: the all-reduce stays on the caller's stream, no hand-off
-            if (int e = comm_allreduce_sum(comm, o.delta_out + lo, hi - lo, st)) return e;
-            break;
-        }
+        if (nc == 1)    // nothing to overlap with: the all-reduce stays on the caller's stream, no hand-off
+            return comm_allreduce_sum(comm, o.delta_out + lo, hi - lo, st);
         // this range's sums are complete on `stream`: hand them to the comm stream
         HIP_TRY(hipEventRecord(comm->ev_ready[c], st));
         HIP_TRY(hipStreamWaitEvent(comm->stream, comm->ev_ready[c], 0));
+        on_comm = true;
         if (int e = comm_allreduce_sum(comm, o.delta_out + lo, hi - lo, comm->stream)) return e;
         if (apply_ranges)
-            if (int e = apply_delta_rows(ctx, p, mirror, mirror_bytes, pieces, o.delta_out, o.lr, 7, bound[c], bound[c + 1], c + 1 == nc, comm->stream))
-                return e;
+            return apply_delta_rows(ctx, p, mirror, mirror_bytes, pieces, o.delta_out, o.lr, 7, bound[c], bound[c + 1], c + 1 == nc, comm->stream);
+        return KURBM_OK;
+    };
+    for (int c = 0; c < nc && !err; ++c) err = range(c);
+    if (on_comm) {   // (also on the error path: see above)
+        const std::string keep = g_err;
+        const hipError_t e1 = hipEventRecord(comm->ev_done, comm->stream);
+        const hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(st, comm->ev_done, 0) : e1;
+        if (err) g_err = keep;
+        else if (e2 != hipSuccess) err = fail(KURBM_ERR_HIP, "joining the comm stream: %s", hipGetErrorString(e2));
     }
-    if (nc > 1) {
-        HIP_TRY(hipEventRecord(comm->ev_done, comm->stream));
-        HIP_TRY(hipStreamWaitEvent(st, comm->ev_done, 0));
-    }
+    if (err) return err;
     if (opts->apply && !apply_ranges) {
         if (pieces == 3) return kurbm_x3_apply_delta(ctx, p, mirror, mirror_bytes, o.delta_out, o.lr, 7, stream);
         if ((p->n_hid & 3) == 0) return apply_delta_rows(ctx, p, mirror, mirror_bytes, pieces, o.delta_out, o.lr, 7, 0, p->n_vis, true, st);

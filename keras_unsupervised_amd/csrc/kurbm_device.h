@@ -11,28 +11,37 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // they are needed: k_gemm_pb's entry waited for SEVEN scalar loads one after the other, ~7 000 cycles (3.3 us) between a wave's
 // first instruction and its first request for data (s_memtime stamps).  Touch every 64-byte line
 // of the segment at once, wait once: the argument loads behind this hit in the scalar cache.
-// (Inline asm: as plain loads hipcc folds them into its own argument loads and waits three times.  Every destination register
-//  stays live until the one wait, so nothing else is allocated to a register a load is still in flight to.)
+// (Inline asm: as plain loads hipcc folds them into its own argument loads and waits three times.  ONE asm statement holds
+//  every load AND the wait: the destination registers are early-clobber outputs that nothing reads, so the compiler can neither
+//  copy nor spill one while a load is still in flight to it, and its own lgkmcnt bookkeeping never sees these loads pending --
+//  the statement ends with the counter at zero (scalar loads return out of order, so the compiler's own waits for whatever it
+//  had in flight are lgkmcnt(0) too and stay correct).  Up to 12 lines = 768 bytes; a shorter segment
+//  repeats its last line, so no load reaches past the segment.)
 typedef const __attribute__((address_space(4))) void* kernarg_ptr_t;
-template <int OFF, int END>
-struct KernargWarm {
-    static __device__ __forceinline__ void go(kernarg_ptr_t ka) {
-        uint32_t d;
-        asm volatile("s_load_dword %0, %1, %2" : "=s"(d) : "s"(ka), "i"(OFF));
-        KernargWarm<OFF + 64, END>::go(ka);
-        asm volatile("" ::"s"(d));
-    }
-};
-template <int END>
-struct KernargWarm<END, END> {
-    static __device__ __forceinline__ void go(kernarg_ptr_t) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-};
+template <int NBYTES>
+__device__ __forceinline__ void kernarg_warm(kernarg_ptr_t ka) {
+    constexpr int L = (NBYTES + 63) / 64;
+    static_assert(L >= 1 && L <= 12, "argument segment: at most 12 lines of 64 bytes");
+#define KURBM_KA_OFF(i) "i"(64 * ((i) < L ? (i) : L - 1))
+    uint32_t d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11;
+    asm volatile(
+        "s_load_dword %0, %12, %13\n\ts_load_dword %1, %12, %14\n\ts_load_dword %2, %12, %15\n\ts_load_dword %3, %12, %16\n\t"
+        "s_load_dword %4, %12, %17\n\ts_load_dword %5, %12, %18\n\ts_load_dword %6, %12, %19\n\ts_load_dword %7, %12, %20\n\t"
+        "s_load_dword %8, %12, %21\n\ts_load_dword %9, %12, %22\n\ts_load_dword %10, %12, %23\n\ts_load_dword %11, %12, %24\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9), "=&s"(d10),
+          "=&s"(d11)
+        : "s"(ka), KURBM_KA_OFF(0), KURBM_KA_OFF(1), KURBM_KA_OFF(2), KURBM_KA_OFF(3), KURBM_KA_OFF(4), KURBM_KA_OFF(5), KURBM_KA_OFF(6),
+          KURBM_KA_OFF(7), KURBM_KA_OFF(8), KURBM_KA_OFF(9), KURBM_KA_OFF(10), KURBM_KA_OFF(11)
+        : "memory");
+#undef KURBM_KA_OFF
+}
 #ifndef KURBM_WARM_ARGS
 #define KURBM_WARM_ARGS 1   // (0: A/B builds)
 #endif
 template <int NBYTES>
 __device__ __forceinline__ void warm_kernel_arguments() {
-    if (KURBM_WARM_ARGS) KernargWarm<0, (NBYTES + 63) / 64 * 64>::go((kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr());
+    if (KURBM_WARM_ARGS) kernarg_warm<NBYTES>((kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 // ------------------------------------------------------------------------------------

@@ -218,12 +218,19 @@ class DeviceRBM:
                 v.bf16_exact, v.binary = (bits & 1) == 0, bits == 0
         return 1 if v.bf16_exact else 3
 
-    def get_weights(self):
-        out = self.W.to_numpy(), self.b_h.cpu().numpy(), self.b_v.cpu().numpy()     # (device -> host copies: a sync)
+    def check_status(self):
+        """Raise if a kernel of this context reported a problem (kurbm_ctx_status; synchronises with the device).  The only
+        bit there is: a statistics launch that reduces its own slabs (KURBM_X3_FUSED=1, off by default) gave up waiting for
+        the other k-slices of its tile and left W and its mirror partly updated -- training must not go on from that state."""
         bits = self.ctx.status()
         if bits:
             raise _lib.KurbmError("kurbm status %#x: a statistics launch that reduces its own slabs (KURBM_X3_FUSED=1) found its "
-                                  "grid not resident (CU mask / shared device) and skipped an update of W" % bits)
+                                  "grid not resident (CU mask / shared device) and skipped an update of W; the weights and their "
+                                  "bf16 mirror are inconsistent -- reload them (set_weights) and train with KURBM_X3_FUSED=0" % bits)
+
+    def get_weights(self):
+        out = self.W.to_numpy(), self.b_h.cpu().numpy(), self.b_v.cpu().numpy()     # (device -> host copies: a sync)
+        self.check_status()
         return out
 
     def set_weights(self, W=None, b_h=None, b_v=None):
@@ -336,9 +343,9 @@ class DeviceRBM:
         """One data-parallel CD-k update: this rank's chain on rows [row_start, +rows) of v (`row0` = their index in
         the global batch), the packed sums all-reduced over `comm` (dp.Comm), the summed update applied.  rows may be 0
         (a rank without rows of a remainder batch still joins the all-reduce).  On the x3 and rounded-bf16 paths all of it
-        is ONE library call (kurbm_cd_step_x3_dp / _bf16_dp) that, above 8 MB of sums, cuts dW into row ranges and
-        all-reduces + applies range i on its comm stream under the statistics GEMM of range i + 1; the fp32-MFMA path runs
-        emit -> kurbm_allreduce_sum_f32 -> apply."""
+        is ONE library call (kurbm_cd_step_x3_dp / _bf16_dp): one all-reduce of the packed sums on the launch stream (n_chunks > 1
+        or KURBM_DP_CHUNKS > 1 opts into row ranges of dW, range i all-reduced + applied on the library's comm stream under the
+        statistics GEMM of range i + 1); the fp32-MFMA path runs emit -> kurbm_allreduce_sum_f32 -> apply."""
         delta = self.delta_buffer()
         # n_chunks 0: the library's choice (by the size of the exchange; ctx knob KURBM_DP_CHUNKS overrides)
         if compute in ("x3", "bf16"):

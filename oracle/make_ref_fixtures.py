@@ -38,7 +38,17 @@ SEEDS = (31, 32)            # parameter seeds of the two layers; sampler seeds a
 HPS = {"batch_size": 4, "epochs": 1, "lr": 1e-3}
 
 
+# sha256 of the dbn.py this script was written against and has been read line by line (no imports, no module-level side
+# effects): code from the public reference tree is executed only if it is still THAT file
+REF_DBN_SHA256 = "87b38b3a7df6d080600191e1d21d17a2d7fee8db5e9653d885f5e93d658c673d"
+
+
 def load_reference_dbn():
+    import hashlib
+    with open(REF_DBN, "rb") as f:
+        digest = hashlib.sha256(f.read()).hexdigest()
+    if digest != REF_DBN_SHA256:
+        raise RuntimeError("%s is not the file this script was reviewed against (sha256 %s): not executing it" % (REF_DBN, digest))
     spec = importlib.util.spec_from_file_location("ref_ku_ebm_dbn", REF_DBN)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
