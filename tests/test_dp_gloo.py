@@ -41,6 +41,9 @@ class OracleEngine:
     def get_weights(self):
         return self.W.copy(), self.b_h.copy(), self.b_v.copy()
 
+    def check_status(self):
+        """(DeviceRBM reads the context's sticky status word here; the double has no kernels to report)"""
+
     def cd_step_dp(self, comm, v, rows, row_start, lr, seed, step, k=1, mode=0, chain=0, row0=0, v_chain=None,
                    v_chain_row=0, compute="x3", n_chunks=0, planes=None):
         from keras_unsupervised_amd.ebm import dp
