@@ -20,7 +20,8 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_BSHARE, KN_COUNT };
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_BSHARE, KN_X3_PAIR, KN_X3_SPLIT_STATS,
+       KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_LDPAD", 0},            // extra elements per bf16 plane row (L2 channel camping probe: no effect)
@@ -44,6 +45,11 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_MAP_SLOW", 0},         // 1: k_gemm_pb maps its blocks by integer division (the path of grids too large for the multiply-high
                                    //    constants: tests)
     {"KURBM_X3_BSHARE", 1},        // 0: the three segments of a real-valued A operand one after the other, each staging its own B pieces
+    {"KURBM_X3_PAIR", 1},          // 0: a real-valued A operand walks three tiles per k position on 256 x 64 tiles (round 3); 1: two tiles per
+                                   //    position on 128 x 128 tiles (k_gemm_pb, "BSP")
+    {"KURBM_X3_SPLIT_STATS", 1},   // 0: the statistics of real-valued data in ONE launch (round 3: three one-piece positive tiles per k position);
+                                   //    1: two launches -- the positive half as the transposed problem h_pos^T (bytes) x the pieces of v_pos^T, the
+                                   //    negative half on byte planes (Bernoulli visibles) or on the paired walk (Gaussian visibles)
 };
 
 struct kurbm_ctx {
@@ -673,6 +679,36 @@ static int pb_codes(const kurbm_ctx* ctx, int a_pieces, int b_pieces, unsigned s
     return nseg;
 }
 
+// The statistics of REAL-VALUED data (x3, v_pieces = 3) as two launches (KURBM_X3_SPLIT_STATS).
+//   positive:  the transposed problem -- A = h_pos^T [n_hid][batch] as a k-permuted byte plane, B = the three pieces of v_pos^T
+//              [n_vis][batch]; 256 x 64 tiles of (hidden x visible) that leave transposed into ordinary slabs;
+//   negative:  Bernoulli visibles: A = v_neg^T as bytes, B = the pieces of -h_neg^T, 256 x 64 tiles (the plain byte-plane walk);
+//              Gaussian visibles: A = the three pieces of v_neg^T, B = those of -h_neg^T, 128 x 128 tiles on the paired walk.
+// Each launch cuts k into slices of whole 128-deep blocks so that its grid fills the chip; the slabs of both are summed by the
+// one reduce launch (negative slabs first).
+struct SplitStats { OuterPlanB pos, neg; };
+static SplitStats plan_split_stats(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid, bool gauss, int s_max = 1 << 30) {
+    SplitStats sp;
+    const int nkt = round_up(rows, 128) / 64;
+    auto fill = [&](OuterPlanB& pl, int gm, int gn, int cfg, int per) {
+        pl.gm = gm; pl.gn = gn; pl.cfg = cfg;
+        pl.nkt = nkt; pl.kt_total = per * nkt;
+        int s = ctx->knob[KN_BF16_SPLIT] != KN_AUTO ? ctx->knob[KN_BF16_SPLIT] : ctx->ncu / (gm * gn);
+        if (s > s_max) s = s_max;      // (a row range of the statistics keeps inside the slab memory carved for the whole matrix)
+        if (s < 1) s = 1;
+        if (s > nkt / 2) s = nkt / 2;
+        if (s < 1) s = 1;
+        pl.nsplit_bound = s;
+        pl.kt_per_split = round_up(ceil_div(pl.kt_total, s), 2 * per);      // whole 128-deep blocks (two k positions)
+        pl.nsplit = ceil_div(pl.kt_total, pl.kt_per_split);
+        pl.ld_slab = round_up(n_hid, 4);
+    };
+    fill(sp.pos, ceil_div(n_hid, 256), ceil_div(n_vis, 64), 2, 1);
+    if (gauss) fill(sp.neg, ceil_div(n_vis, 128), ceil_div(n_hid, 128), 0, 3);
+    else fill(sp.neg, ceil_div(n_vis, 256), ceil_div(n_hid, 64), 2, 1);
+    return sp;
+}
+
 static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_vis, int n_hid, int pieces, int v_pieces) {
     WorkspaceB w;
     w.Kv = round_up(n_vis, 128);
@@ -703,7 +739,13 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     // (k_gemm_pb writes one row per 64-row half of a 128-row tile: two rows per tile)
     w.part_h = take32((size_t)4 * w.max_row_tiles * w.ldh32);
     w.part_v = take32((size_t)(ceil_div(rows, 64) + 2 * w.max_row_tiles) * w.ldv32);
-    w.slab = take32(w.slab_stride * pl.nsplit_bound);
+    int nslab_res = pl.nsplit_bound;
+    if (pieces == 3 && v_pieces == 3) {   // (the mode is not known here: room for either negative launch)
+        const SplitStats b = plan_split_stats(ctx, rows, n_vis, n_hid, false), gs = plan_split_stats(ctx, rows, n_vis, n_hid, true);
+        const int need = b.pos.nsplit_bound + (b.neg.nsplit_bound > gs.neg.nsplit_bound ? b.neg.nsplit_bound : gs.neg.nsplit_bound);
+        if (need > nslab_res) nslab_res = need;
+    }
+    w.slab = take32(w.slab_stride * nslab_res);
     w.tmp32 = take32((size_t)rows * (w.ldh32 > w.ldv32 ? w.ldh32 : w.ldv32));       // fp32 plane for the test hook
     w.sync = reinterpret_cast<unsigned*>(take32(SYNC_WORDS));
     // the score of fit(verbose = 1): softplus row partials of F(v) and F(v') per 64-column tile, |F - F'| per row
@@ -770,6 +812,9 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         // a real-valued A operand: its three segments per k position, so that they can share one staging of the B pieces
         // (k_gemm_pb, "BSH"; launch_gemm_pb checks the pattern)
         if (g.nseg == 3 && ctx->knob[KN_X3_BSHARE]) { g.seg_fastest = 1; g.inv_nseg = inv_of(3); }
+        // ... and on 128 x 128 tiles as TWO tiles per k position (the paired walk): the tile count, not the bytes, sets that loop's time
+        const bool pair = g.nseg == 3 && g.seg_fastest && m.pieces == 3 && ctx->knob[KN_X3_PAIR] != 0;
+        g.pair_ok = pair ? 1 : 0;
         g.a_bytes = a_bytes ? 1 : 0;   // (a byte plane of 0/1 values: one piece, lda bytes between its rows)
         g.cfg = 0;
         // 2: 256 x 64 tiles (fewer bytes per k-tile).  Whole 256-row tiles only: the bias partial rows are laid out
@@ -778,7 +823,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         // (x3 only: with ONE piece per weight the B tile is the light operand and 128 x 128 tiles take fewer bytes per MFMA --
         //  A 16 KB + B 16 KB against 32 + 8 for the same 128 MFMAs per wave pair; 4096 x 4096 PCD-10, 1024 rows: 0.977 against
         //  1.033 ms per step)
-        if (!g.cfg && ceil_div(rows, 128) % 2 == 0 &&
+        if (!g.cfg && !pair && ceil_div(rows, 128) % 2 == 0 &&
             (tall == 1 || (tall < 0 && m.pieces == 3 && (rows / 256) * ceil_div(g.N, 64) * 4 >= 3 * ctx->ncu))) g.cfg = 2;
         // (64-column tiles: a row-major plane is the next GEMM's A operand, k-padded to 128 -- cover the padded row)
         g.grid_m = ceil_div(rows, g.cfg == 2 ? 256 : 128);
@@ -884,6 +929,11 @@ static int check_cd_args(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_p
     return KURBM_OK;
 }
 
+// (v_pieces without the KURBM_V_BINARY bit) the statistics of this step run as two launches: x3 on real-valued data, byte planes on
+static bool split_stats_on(const kurbm_ctx* ctx, int pieces, int v_pieces) {
+    return pieces == 3 && v_pieces == 3 && ctx->knob[KN_X3_SPLIT_STATS] != 0 && ctx->knob[KN_X3_BYTES] != 0;
+}
+
 static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                        const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace,
                        size_t workspace_bytes, kurbm_stream_t stream, int only = -1, int m_lo = 0, int m_hi = -1) {
@@ -918,6 +968,9 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     // ... and v_neg^T, the A operand of the statistics GEMM's negative half, where the positive half runs on fp8 planes (the
     // walk is then whole units of fp8 / 3-piece / 3-piece tiles: k_gemm_pb<..., EPI_SLAB, ..., AB>): 32 KB per 128 k, not 64
     const bool tbytes = f8pos && nbytes && ctx->knob[KN_X3_STATS_BYTES] != 0 && ctx->knob[KN_X3_STATS_TALL] != 0 && p->n_vis > 128;
+    // real-valued data: the statistics as two launches (plan_split_stats), h_pos^T -- and v_neg^T of Bernoulli visibles -- as byte planes
+    const bool split_stats = split_stats_on(ctx, pieces, v_pieces);
+    const bool tbytes_n = tbytes || (split_stats && nbytes);
     int e;
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
@@ -937,7 +990,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     RngArgs r = make_rng(o->seed, o->row0, base + 0u, o->step);
     if (KURBM_STAGE(1)) {
         HalfOutB ho;
-        ho.out = w.hb; ho.ldo = w.Lh; ho.out_bytes = hbytes; ho.outT = w.hbT; ho.ldoT = w.Lb; ho.outT_f8 = f8pos;
+        ho.out = w.hb; ho.ldo = w.Lh; ho.out_bytes = hbytes; ho.outT = w.hbT; ho.ldoT = w.Lb; ho.outT_f8 = f8pos; ho.outT_b8 = split_stats;
         ho.colpart = w.part_h; ho.ld_colpart = w.ldh32; ho.colsign = 1.f;
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.vb, w.Lv, v_pieces, w.planeV, rows, act_h, NOISE_BERNOULLI, &r, ho, st, vbytes))) return e;
     }
@@ -959,7 +1012,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             HalfOutB ho;
             ho.out = w.v2b; ho.ldo = w.Lv; ho.out_pieces = vn_pieces; ho.out_plane = w.planeV; ho.out_bytes = nbytes;
             if (last) {
-                ho.outT = w.v2bT; ho.ldoT = w.Lb; ho.outT_pieces = vn_pieces; ho.outT_plane = w.planeVT; ho.outT_b8 = tbytes;
+                ho.outT = w.v2bT; ho.ldoT = w.Lb; ho.outT_pieces = vn_pieces; ho.outT_plane = w.planeVT; ho.outT_b8 = tbytes_n;
                 ho.out_f32 = o->v_chain; ho.ldo32 = ldv;
                 ho.grid_m_out = &gm_v;
             }
@@ -992,8 +1045,13 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     // (kurbm_x3.hip) -- no k_reduce_apply_split launch.  Only where every workgroup of its grid is resident at once (one
     // per CU: the k-slices of a tile wait for each other) and the step applies its update in place; the data-parallel,
     // emit-only, row-range and `which`-restricted forms keep the separate launch.
+    // (a row range [m_lo, m_hi) of the visible units: each half may use half of the slabs carved for the whole matrix)
+    const SplitStats sps0 = plan_split_stats(ctx, rows, p->n_vis, p->n_hid, gauss);
+    const SplitStats sps = sub ? plan_split_stats(ctx, rows, Mr, p->n_hid, gauss,
+                                                  (int)((w.slab_stride * (size_t)(sps0.neg.nsplit_bound + sps0.pos.nsplit_bound)) / ((size_t)Mr * sps0.pos.ld_slab) / 2))
+                               : sps0;
     const bool fuse = ctx->knob[KN_X3_FUSED] != 0 && !ctx->knob[KN_UNFUSED_MIRROR] && need_w && ap && (which & 1) && !o->delta_out &&
-                      !sub && (only < 0 || only == 4) && pl.gm * pl.gn * pl.nsplit <= ctx->ncu && pl.gm * pl.gn <= SYNC_WORDS &&
+                      !sub && !split_stats && (only < 0 || only == 4) && pl.gm * pl.gn * pl.nsplit <= ctx->ncu && pl.gm * pl.gn <= SYNC_WORDS &&
                       (size_t)pl.nsplit * slab_stride * 4 < 0x7FFFFFFFull;
     // h_neg = sigmoid(v_neg.W + b_h), probabilities (rbm.py:124): only its transposed image is needed, and only by the
     // statistics GEMM, where it enters with a minus sign: it is stored as -h_neg
@@ -1006,7 +1064,7 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st, nbytes))) return e;
     }
 
-    int nslab_used = pl.nsplit;
+    int nslab_used = split_stats ? sps.neg.nsplit + sps.pos.nsplit : pl.nsplit;
     ReduceArgs a;
     memset(&a, 0, sizeof a);
     a.slab = w.slab; a.slab_stride = slab_stride; a.ld_slab = pl.ld_slab;
@@ -1035,7 +1093,52 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = pieces;
         a.tile_rows = ctx->knob[KN_REDUCE_TR];
     }
-    if (need_w && KURBM_STAGE(4)) {
+    if (need_w && split_stats && KURBM_STAGE(4)) {
+        // ---- negative half: slabs [0, neg.nsplit)
+        {
+            const OuterPlanB& q = sps.neg;
+            GemmArgsB g;
+            memset(&g, 0, sizeof g);
+            g.A0 = w.v2bT + (size_t)m_lo * w.Lb; g.a_plane0 = w.planeVT; g.B0 = w.hnT; g.b_plane0 = w.planeHT;
+            g.lda = w.Lb; g.ldb = w.Lb;
+            g.M = Mr; g.N = p->n_hid; g.K = w.Kb;
+            g.grid_m = q.gm; g.grid_n = q.gn; g.cfg = q.cfg;
+            g.slab = w.slab; g.slab_stride = slab_stride; g.ld_slab = q.ld_slab;
+            g.pb_max = 3;
+            if (gauss) {   // (v_neg piece a) x (-h_neg pieces 0 .. 2 - a), two tiles per k position (k_gemm_pb, "BSP")
+                g.nseg = pb_codes(ctx, 3, 3, 0u, &g.seg_codes, 0);
+                g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg); g.pair_ok = 1;
+            } else {       // v_neg^T as bytes against the three pieces of -h_neg^T (k_gemm_pb, "ABP")
+                g.nseg = pb_codes(ctx, 1, 3, 0u, &g.seg_codes, 0);
+                g.a_bytes = 1; g.lda = 2 * w.Lb;
+            }
+            g.m_fastest = ctx->knob[KN_X3_STATS_MFAST];
+            g.nkt = q.nkt; g.inv_nkt = inv_of(g.nkt);
+            g.kt_total = q.kt_total; g.kt_per_split = q.kt_per_split; g.nsplit = q.nsplit;
+            g.xcd2d = ctx->knob[KN_X3_XCD2D]; g.map_force = ctx->knob[KN_MAP_SLOW];
+            g.any_order = (ctx->knob[KN_ANYORDER] >> 1) & 1;
+            HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
+        }
+        // ---- positive half, transposed: h_pos^T (bytes) x the pieces of v_pos^T -> slabs [neg.nsplit, +pos.nsplit)
+        {
+            const OuterPlanB& q = sps.pos;
+            GemmArgsB g;
+            memset(&g, 0, sizeof g);
+            g.A0 = w.hbT; g.a_bytes = 1; g.lda = 2 * w.Lb;
+            g.B0 = w.vbT + (size_t)m_lo * w.Lb; g.b_plane0 = w.planeVT; g.ldb = w.Lb;
+            g.M = p->n_hid; g.N = Mr; g.K = w.Kb;
+            g.grid_m = q.gm; g.grid_n = q.gn; g.cfg = q.cfg;
+            g.slab = w.slab + (size_t)sps.neg.nsplit * slab_stride; g.slab_stride = slab_stride; g.ld_slab = q.ld_slab; g.slab_t = 1;
+            g.pb_max = 3;
+            g.nseg = pb_codes(ctx, 1, 3, 0u, &g.seg_codes, 0);
+            g.m_fastest = ctx->knob[KN_X3_STATS_MFAST];
+            g.nkt = q.nkt; g.inv_nkt = inv_of(g.nkt);
+            g.kt_total = q.kt_total; g.kt_per_split = q.kt_per_split; g.nsplit = q.nsplit;
+            g.xcd2d = ctx->knob[KN_X3_XCD2D]; g.map_force = ctx->knob[KN_MAP_SLOW];
+            g.any_order = (ctx->knob[KN_ANYORDER] >> 1) & 1;
+            HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
+        }
+    } else if (need_w && KURBM_STAGE(4)) {
         GemmArgsB g;
         memset(&g, 0, sizeof g);
         g.A0 = w.vbT + (size_t)m_lo * w.Lb; g.a_plane0 = w.planeVT; g.B0 = w.hbT;
@@ -1268,12 +1371,15 @@ int kurbm_x3_dump_plane(kurbm_ctx* ctx, int which, int rows, int n_vis, int n_hi
     a.out = out; a.rows = rows; a.ld_out = ld_out; a.pieces = 1; a.sign = 1.f;
     switch (which) {
         case KURBM_PLANE_H_POS:   a.src = w.hb;   a.units = n_hid; a.ld = w.Lh; a.fmt = byt ? 1 : 0; break;
-        case KURBM_PLANE_H_POS_T: a.src = w.hbT;  a.units = n_hid; a.ld = w.Lb; a.fmt = f8pos ? 2 : 0; a.transposed = 1; break;
+        case KURBM_PLANE_H_POS_T: a.src = w.hbT;  a.units = n_hid; a.ld = w.Lb; a.fmt = f8pos ? 2 : 0; a.transposed = 1;
+                                  if (split_stats_on(ctx, 3, v_pieces)) { a.fmt = 1; a.ld = 2 * w.Lb; }   // (bytes at the bf16 plane's row stride)
+                                  break;
         case KURBM_PLANE_V_NEG:   a.src = w.v2b;  a.units = n_vis; a.ld = w.Lv; a.fmt = (byt && !gauss) ? 1 : 0;
                                   a.pieces = gauss ? 3 : 1; a.plane = w.planeV; break;
         case KURBM_PLANE_V_NEG_T: a.src = w.v2bT; a.units = n_vis; a.ld = w.Lb; a.transposed = 1;
                                   a.pieces = gauss ? 3 : 1; a.plane = w.planeVT;
-                                  if (f8pos && byt && !gauss && ctx->knob[KN_X3_STATS_BYTES] != 0 && ctx->knob[KN_X3_STATS_TALL] != 0 && n_vis > 128) {
+                                  if ((f8pos && byt && !gauss && ctx->knob[KN_X3_STATS_BYTES] != 0 && ctx->knob[KN_X3_STATS_TALL] != 0 && n_vis > 128) ||
+                                      (split_stats_on(ctx, 3, v_pieces) && !gauss)) {
                                       a.fmt = 1; a.ld = 2 * w.Lb;   // (bytes at the bf16 plane's row stride: cd_step_any, tbytes)
                                   }
                                   break;

@@ -228,7 +228,8 @@ struct GemmArgsB {
     int m_fastest;
     int a_bytes;          // the A operand is such a byte plane (lda bytes between its rows; one segment): k_gemm_pb<..., AB>
     int bshare;           // (launcher) a real-valued A operand on three-piece weights: segments (A piece p) x (B pieces 0 .. 2 - p), walked
-                          // segment-fastest -- the three tiles of a k position share ONE staging of its B pieces (k_gemm_pb, "BSH")
+                          // segment-fastest -- the three tiles of a k position share ONE staging of its B pieces (k_gemm_pb, "BSH");
+                          // 2: ... as TWO tiles per position on 128 x 128 tiles (the paired walk, "BSP")
     int bshare2;          // (launcher) statistics GEMM of real-valued data: per k position `bsh_np` positive segments (A piece p of set 0 x B
     int bsh_np;           // piece 0 of set 0) and then the negative ones (set 1, first with three B pieces): the tiles of a k position share
                           // one staging of the position's B pieces -- 1 + 3 -- and the A tiles ring through three stages (k_gemm_pb, "BSH2")
@@ -272,7 +273,10 @@ struct GemmArgsB {
     float* slab;
     size_t slab_stride;
     int ld_slab;
+    int slab_t;           // EPI_SLAB on a byte-plane A operand (k_gemm_pb "ABP"): the tile leaves TRANSPOSED -- M counts the slab's COLUMNS,
+                          // N its rows (the positive statistics of real-valued data as h_pos^T x the pieces of v_pos^T)
     int bshare_ok;        // caller: the statistics GEMM may share B stagings between the tiles of a k position (ctx knob KURBM_X3_BSHARE)
+    int pair_ok;          // caller: a real-valued A operand on 128 x 128 tiles may walk two tiles per k position (ctx knob KURBM_X3_PAIR; bshare = 2)
     int map_force;        // caller: 1 = map blocks by division whatever the grid (ctx knob KURBM_MAP_SLOW: tests of that path)
     int any_order;        // caller: TIMING ONLY -- launch without the AQL barrier bit (ctx knob KURBM_ANYORDER); results race
     int xcd2d;            // caller: 1 = let the launcher pick such blocks (ctx knob KURBM_X3_XCD2D), 0 = the linear order

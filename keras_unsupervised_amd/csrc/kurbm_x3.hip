@@ -137,14 +137,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // plane like the half steps' A operand (32 KB per 128 k where the bf16 plane is 64: this launch is bound by the bytes a CU
     // can take in, ~34 per cycle).  Only the fixed walk fp8 / 3-piece / 3-piece (g.walk3); the fp8 tile is scaled x 2 through
     // its E8M0 exponent so that the slab epilogue's halving (0x40 bytes are 2.0) leaves it alone.
-    constexpr bool ABS = AB && EPI == EPI_SLAB;
-    static_assert(!ABS || (PB == 3 && !RP), "byte-plane statistics: three-piece negative half");
+    constexpr bool ABS = AB && EPI == EPI_SLAB && !RP;
+    static_assert(!ABS || PB == 3, "byte-plane statistics: three-piece negative half");
+    // ABP (template slot RP on EPI_SLAB): a statistics GEMM whose A operand is ONE byte plane and whose k range is one segment of
+    // three-piece tiles -- the plain byte-plane walk of the half steps with the slab epilogue, any number of k slices of whole
+    // 128-deep blocks.  Two launches of real-valued data use it: the NEGATIVE statistics of Bernoulli visibles (A = v_neg^T, 0/1;
+    // B = the pieces of -h_neg^T) and the POSITIVE statistics as the transposed problem (A = h_pos^T, 0/1; B = the three pieces of
+    // v_pos^T: one 40-KB tile per k position where the untransposed walk staged three 40-KB tiles of one piece each), whose tile
+    // leaves TRANSPOSED (g.slab_t) so that its slabs look like everyone else's.
+    constexpr bool ABP = AB && EPI == EPI_SLAB && RP;
+    static_assert(!ABP || PB == 3, "plain byte-plane statistics: three-piece tiles");
     constexpr int A_BYTES = BM * ROWB, B1_BYTES = BN * ROWB, B_BYTES = PB * B1_BYTES;   // (AB: A_BYTES is a BLOCK, 128 k deep)
     // DEEP: one-piece tiles of bytes (the rounded-bf16 path's half steps on 0/1 states) -- 16 MFMAs per wave and tile, a third
     // of a DMA round trip -- run a deeper pipeline than the three-piece tiles have room for: FOUR B stages and THREE A blocks,
     // tiles requested four ahead, fragments read two micro-steps (= one tile) ahead ACROSS the tile's barrier (see `deep_tile`)
     constexpr bool DEEP = AB && PB == 1;
-    constexpr int NAB = (DEEP || (AB && EPI == EPI_SLAB)) ? 3 : 2;     // A block buffers (AB)
+    constexpr int NAB = (DEEP || ABS) ? 3 : 2;     // A block buffers (AB)
     // LDS: two stages [A tile | B pieces]; AB: the A blocks, then the stages of B pieces
     constexpr int STAGE = AB ? B_BYTES : A_BYTES + B_BYTES;
     constexpr int B_OFF = AB ? NAB * A_BYTES : A_BYTES;
@@ -152,21 +160,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     static_assert((BM * CPR) % NTS == 0 && (BN * CPR) % NTS == 0 && NA % 2 == 0, "whole pieces per loader wave");
     constexpr int PROW16 = 2 * BN + 16;   // bf16 patch row (bytes)
     constexpr int PROW32 = 4 * BN + 16;   // fp32 patch row (bytes)
-    constexpr int PATCH_BYTES = (EPI == EPI_SOFTPLUS) ? WAVES_N * BM * 4 : BM * (EPI == EPI_SLAB ? PROW32 : PROW16);
+    constexpr int PROWT = 4 * BM + 16;    // fp32 patch row of a tile that leaves transposed (ABP, g.slab_t): BN rows of BM floats
+    constexpr int PATCH_BYTES0 = (EPI == EPI_SOFTPLUS) ? WAVES_N * BM * 4 : BM * (EPI == EPI_SLAB ? PROW32 : PROW16);
+    constexpr int PATCH_BYTES = (ABP && BN * PROWT > PATCH_BYTES0) ? BN * PROWT : PATCH_BYTES0;
     // One-piece tiles (the rounded-bf16 path) are 16 MFMAs per wave, shorter than the round trip of a tile's DMA: THREE
     // stages, tiles requested two ahead.  (Three-piece tiles: two stages fill the LDS.)
     constexpr int NSTG = DEEP ? 4 : (PB == 1) ? 3 : 2;
     // (AB: NAB A blocks of 128 k beside NSTG stages of B pieces, the A blocks requested half a block per tile)
     // (byte-plane statistics: three A blocks, a B stage for each of the two 3-piece tiles of a unit and one PIECE for its fp8 tile)
-    constexpr int STAGES_BYTES = (AB && EPI == EPI_SLAB) ? NAB * A_BYTES + 2 * B_BYTES + B1_BYTES
+    constexpr int STAGES_BYTES = ABS ? NAB * A_BYTES + 2 * B_BYTES + B1_BYTES
                                : AB ? NAB * A_BYTES + NSTG * B_BYTES : NSTG * (A_BYTES + B_BYTES);
     // BSH (g.bshare; non-AB three-piece half steps: a real-valued A operand): THREE A stages and two B stages -- the three tiles
     // of a k position (A piece 0 x B pieces 0-2, piece 1 x 0-1, piece 2 x 0) share one staging of that position's B pieces:
     // 120 instead of 144 KB per k position, and the third A stage lets a counted vmcnt keep a tile in flight across the barrier
     // (with two [A | B] stages the loaders waited for the tile they had just requested: issue + landing = the tile's time).
     constexpr bool BSH = !AB && PB == 3 && EPI == EPI_HALFSTEP;
-    constexpr int BSH_BYTES = 3 * A_BYTES + 2 * B_BYTES, BSH_BOFF = 3 * A_BYTES;
-    constexpr int SMEM_BYTES0 = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
+    // BSP (g.bshare == 2; 128 x 128 tiles only): the PAIRED walk of a real-valued A operand -- per k position TWO tiles of 48 MFMAs per
+    // wave each, (A piece 0) x (B pieces 0-2) and then (piece 1) x (0-1) together with (piece 2) x (0) -- instead of three tiles of
+    // 48 / 32 / 16: a tile costs its barrier and its restart whatever is in it (one-piece tiles of 512 matrix-pipe
+    // cycles took ~1 500).  The second tile reads TWO A tiles, so the A tiles ring through FOUR stages (16 KB each on this tiling)
+    // beside the two B stages: 160 KB.  The half steps on grey-level data / Gaussian visibles, and the negative statistics of
+    // Gaussian visibles (EPI_SLAB) walk it.
+    constexpr bool BSP = (BM == 128) && !AB && PB == 3 && (EPI == EPI_HALFSTEP || EPI == EPI_SLAB);
+    constexpr int BSH_NA = (BM == 128) ? 4 : 3;          // A stages of the shared-B layouts
+    constexpr int BSH_BYTES = BSH_NA * A_BYTES + 2 * B_BYTES, BSH_BOFF = BSH_NA * A_BYTES;
+    constexpr int SMEM_BYTES00 = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
+    constexpr int SMEM_BYTES0 = (BSP && BSH_BYTES > SMEM_BYTES00) ? BSH_BYTES : SMEM_BYTES00;
     // BSH2 (g.bshare2; the statistics GEMM of real-valued data): the same ring of three A stages; a B stage holds the k position's
     // positive piece and its three negative pieces (four piece slots)
     constexpr int BSH2_BYTES = 3 * A_BYTES + 2 * 4 * B1_BYTES;
@@ -376,7 +395,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // AB: `ablk` = the block buffer (0 / 1) of the tile pair in work; tile `buf` (= its parity) is half `buf` of the block's k
     int ablk = 0;
     const bool bsh2 = BSH2 && g.bshare2 != 0;
-    const bool bsh = (BSH && g.bshare != 0) || bsh2;   // (wave-uniform; BSH: the stage arguments are compile-time constants at every call)
+    const bool bsp = BSP && g.bshare == 2;
+    const bool bsh = (BSH && g.bshare != 0) || bsh2 || bsp;   // (wave-uniform; BSH: the stage arguments are compile-time constants at every call)
     const int bsh_bstride = bsh2 ? 4 * B1_BYTES : B_BYTES;   // (a B stage: the three pieces; BSH2: four piece slots)
     auto frag_a = [&](int buf, int ks, afrag (&f)[TM], int blk_step = 0) __attribute__((always_inline)) {
         if constexpr (AB) {   // tile `buf` of the block, lane group `slot`: chunk 4 buf + slot of the 128-byte row (k-permuted plane)
@@ -508,6 +528,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
+    };
+    // The second tile of a k position on the paired walk (BSP): (A piece 1) x (B pieces 0, 1) and (A piece 2) x (B piece 0), 2 x 3 micro-
+    // steps of 8 MFMAs like a three-piece tile.  Entered with fa[0] = A1 and fb[0] = B0 of k-step 0 (the tile in front read them
+    // behind its barrier); A1 alternates between fa[0] / fa[1] with the k-step, A2 has a set of its own (the k loop has the
+    // registers: accumulators 32 + fragments 56 + 16), B rotates through the three fb sets.  Every read is two micro-steps ahead of
+    // its MFMAs except the two that catch up at u = 0; the tile's ONE barrier in front of the last micro-step, as in one_tile.
+    [[maybe_unused]] afrag fa2[BSP ? TM : 1];
+    auto pair_tile = [&](const int a1, const int a2, const int bcur, const int anext, const int bnext) __attribute__((always_inline)) {
+        if constexpr (BSP) {
+            __builtin_amdgcn_sched_barrier(0);
+            frag_b(bcur, 0, 1, fb[1]); frag_a(a2, 0, fa2);
+            mfmas(fa[0], fb[0]);                                   // A1 . B0, k-step 0
+            __builtin_amdgcn_sched_barrier(0);
+            frag_a(a1, 1, fa[1]); frag_b(bcur, 1, 0, fb[2]);
+            mfmas(fa[0], fb[1]);                                   // A1 . B1
+            __builtin_amdgcn_sched_barrier(0);
+            frag_b(bcur, 1, 1, fb[1]);
+            mfmas(fa2, fb[0]);                                     // A2 . B0
+            __builtin_amdgcn_sched_barrier(0);
+            frag_a(a2, 1, fa2);
+            mfmas(fa[1], fb[2]);                                   // A1 . B0, k-step 1
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[1], fb[1]);                                   // A1 . B1
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            frag_a(anext, 0, fa[0]);
+            frag_b(bnext, 0, 0, fb[0]);
+            mfmas(fa2, fb[2]);                                     // A2 . B0
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     // An fp8 tile (statistics of 0/1 data, segment 0): the same 128-byte rows hold 128 k.  Lane group g = lane >> 4 of
     // v_mfma_scale_f32_16x16x128_f8f6f4 supplies 32 bytes of its row; which 32 is free as long as A and B agree (k is a
@@ -763,7 +814,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 TileRef ra = tile_of(t_begin);
                 TileRef rb = ra;
                 const uint32_t ob0 = ra.ob;
-                ra.neg = false; ra.oa = 0u;
+                ra.neg = false; ra.oa = 128u * (uint32_t)(t_begin >> 1);   // (a k slice starts on a whole block: launch_pb checks)
                 KURBM_PSTAMP(0);
                 dma_part(0, ra, 3, 0);
                 KURBM_PSTAMP(1);
@@ -849,6 +900,59 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     KURBM_LSTAMP(2);
                     __builtin_amdgcn_s_barrier();
                     KURBM_LSTAMP(3);
+                }
+                KURBM_LSTAMP_OUT();
+            } else if (bsp) {
+                // The paired walk: k position kt = tile T0(kt) [A piece 0 x B pieces 0-2] and tile T1(kt) [A1 x B0-1, A2 x B0].  A tiles
+                // in the order they are consumed, a = 3 kt + piece, live in A stage a & 3; the three B pieces of a position in B
+                // stage kt & 1.  A stage may be refilled once the tile that read it is behind its barrier, so while T0(kt) is
+                // multiplied the stages of A1 / A2(kt - 1) and the B stage of kt - 1 are free, while T1(kt) that of A0(kt):
+                //   slot T0(kt):  A2(kt) -- needed behind this tile's barrier, so it goes FIRST --, B0(kt + 1), B1(kt + 1)
+                //   slot T1(kt):  B2(kt + 1), A0(kt + 1), A1(kt + 1)
+                // 12 pieces per wave and slot; the barrier of T0(kt) waits for everything but the 8 B pieces just requested, that
+                // of T1(kt) for everything but A1(kt + 1): every request but A2's has a whole tile to land.
+                static_assert(!BSP || (NA == 4 && NB1 == 4), "paired walk: 128 x 128 tiles");
+                const int np = nt / 3;                           // (launch_gemm_pb: whole positions per slice)
+                Walk w = walk_at(t_begin);
+                TileRef ra0 = walk_ref(w); walk_next(w);
+                TileRef ra1 = walk_ref(w); walk_next(w);
+                TileRef ra2 = walk_ref(w);
+                TileRef rb = ra0;                                // (B of the position: all three pieces)
+                rb.npb = 3;
+                dma_part(0, ra0, 1); dma_part(0, rb, 2);         // A0(0) -> A stage 0, B(0) -> B stage 0
+                dma_part(1, ra1, 1);                             // A1(0) -> A stage 1
+                __builtin_amdgcn_s_waitcnt(vm(NA));              // A0(0), B(0) have landed
+                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
+                __builtin_amdgcn_s_barrier();
+                int sa = 2;                                      // A stage of tile a = 3 kt + 2
+                for (int kt = 0; kt < np; ++kt) {
+                    const bool more = kt + 1 < np;
+                    KURBM_LSTAMP(0);
+                    // ---- T0(kt) in work
+                    dma_part(sa, ra2, 1);                        // A2(kt)
+                    ra0.oa += 128u; ra1.oa += 128u; ra2.oa += 128u; rb.ob += 128u;   // -> position kt + 1
+                    if (more) {
+                        dma_part((kt + 1) & 1, rb, 2, 0, 0, 0, 0, 2);               // B0, B1(kt + 1)
+                        KURBM_LSTAMP(1);
+                        __builtin_amdgcn_s_waitcnt(vm(2 * NB1));
+                    } else {
+                        KURBM_LSTAMP(1);
+                        __builtin_amdgcn_s_waitcnt(VM0);
+                    }
+                    KURBM_LSTAMP(2);
+                    __builtin_amdgcn_s_barrier();
+                    KURBM_LSTAMP(3);
+                    // ---- T1(kt) in work
+                    if (more) {
+                        dma_part((kt + 1) & 1, rb, 2, 0, 0, 0, 2, 3);               // B2(kt + 1)
+                        dma_part((sa + 1) & 3, ra0, 1);                              // A0(kt + 1): a = 3 kt + 3
+                        dma_part((sa + 2) & 3, ra1, 1);                              // A1(kt + 1): a = 3 kt + 4
+                        __builtin_amdgcn_s_waitcnt(vm(NA));
+                    } else {
+                        __builtin_amdgcn_s_waitcnt(VM0);
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    sa = (sa + 3) & 3;
                 }
                 KURBM_LSTAMP_OUT();
             } else if (bsh) {
@@ -1205,6 +1309,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                         else one_tile(ast, 0, std::integral_constant<int, 1>{}, bst, astn, bstn, pb0, pb0n);
                         seg = segn; ast = astn; bst = bstn;
                     }
+                } else if (bsp) {
+                    // (see the loaders) k position kt: one three-piece tile on A stage (3 kt) & 3, then the paired tile on the next two
+                    const int np = nt / 3;
+                    int s0 = 0;
+                    for (int kt = 0; kt < np; ++kt) {
+                        const int s1 = (s0 + 1) & 3, s2 = (s0 + 2) & 3, s3 = (s0 + 3) & 3, b = kt & 1;
+#ifdef KURBM_STAMPS
+                        unsigned long long tp0, tp1, tp2;
+                        KURBM_STAMP(tp0);
+#endif
+                        one_tile(s0, 0, std::integral_constant<int, 3>{}, b, s1, b);
+#ifdef KURBM_STAMPS
+                        KURBM_STAMP(tp1);
+#endif
+                        pair_tile(s1, s2, b, s3, b ^ 1);
+#ifdef KURBM_STAMPS
+                        KURBM_STAMP(tp2);
+                        tk[2] += tp1 - tp0; tk[1] += tp2 - tp1;     // (three-piece tile / paired tile, summed over the positions)
+#endif
+                        s0 = s3;
+                    }
+                    i = nt;
                 } else if (bsh) {
                     // k position kt = tiles (A piece 0 x 3 B pieces), (piece 1 x 2), (piece 2 x 1): A stage = the piece, B stage =
                     // kt & 1 for all three -- six tiles per trip
@@ -1248,6 +1374,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // C layout: acc[mi][ni][r] is row m0 + wm WM + 16 mi + 4 slot + r, column n0 + wn WN + 16 ni + l15.
     if (EPI == EPI_SLAB) {
         float* slab = g.slab + (size_t)z * g.slab_stride;
+        if constexpr (ABP) {
+            if (g.slab_t) {
+                // The transposed problem: this tile is rows m0.. of B^T A... i.e. element (r, c) of the tile belongs at slab row
+                // n0 + c, column m0 + r.  A lane holds four consecutive r of its column c: one 16-byte write into a [BN][BM] patch
+                // (8 consecutive lanes = 8 rows of the patch, 260 dwords apart: all 32 banks), then whole patch rows leave as
+                // 1-KB runs along the slab's rows.  Tile rows past M (A rows the loaders pointed at row 0) are zeros.
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        const int r = wm * WM + mi * 16 + slot * 4, c = wn * WN + ni * 16 + l15;
+                        f32x4 v = acc[mi][ni] * 0.5f;                           // (the A bytes read as 2.0)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (m0 + r + e >= g.M) v[e] = 0.f;
+                        *reinterpret_cast<f32x4*>(smem + c * PROWT + 4 * r) = v;
+                    }
+                __syncthreads();
+                constexpr int CHT = BM / 4;   // 16-B chunks per patch row
+#pragma unroll
+                for (int j = 0; j < BN * CHT / NT; ++j) {
+                    const int q = j * NT + tid, row = q / CHT, c4 = q % CHT;
+                    const int gr = n0 + row, gc = m0 + 4 * c4;
+                    if (gr < g.N && gc < g.ld_slab)
+                        *reinterpret_cast<f32x4*>(slab + (size_t)gr * g.ld_slab + gc) = *reinterpret_cast<const f32x4*>(smem + row * PROWT + 16 * c4);
+                }
+                KURBM_STAMP_OUT();
+                return;
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -1256,7 +1412,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 for (int r = 0; r < 4; ++r)
                     *reinterpret_cast<float*>(smem + (wm * WM + mi * 16 + slot * 4 + r) * PROW32 +
                                               4 * (wn * WN + ni * 16 + l15)) =
-                        (n0 + wn * WN + ni * 16 + l15 < g.N) ? (ABS ? 0.5f * acc[mi][ni][r] : acc[mi][ni][r]) : 0.f;
+                        (n0 + wn * WN + ni * 16 + l15 < g.N) ? ((ABS || ABP) ? 0.5f * acc[mi][ni][r] : acc[mi][ni][r]) : 0.f;
         __syncthreads();
         constexpr int CH = BN / 4;   // 16-B chunks per row
         if (!g.fuse) {
@@ -1805,6 +1961,7 @@ static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
     // byte A planes: ONE segment of PBN pieces, one k slice -- those kernels' loops do not walk a tile list
     // (the statistics GEMM on byte planes: its own fixed walk, any number of k slices -- checked where it is launched)
     if (g.a_bytes && E != EPI_SLAB && (g.nseg != 1 || g.nsplit != 1 || (int)((g.seg_codes >> 2) & 3u) != PBN)) return hipErrorInvalidValue;
+    if (g.slab_t && !(g.a_bytes && E == EPI_SLAB)) return hipErrorInvalidValue;   // (only the plain byte-plane statistics kernel writes transposed)
     if constexpr (E == EPI_HALFSTEP && PBN == 3 && (NZ == NOISE_BERNOULLI || NZ == NOISE_NONE)) {
         if (g.rp) {   // the score's half steps: (samples AND) the softplus row sums of their rows
             if (!g.rowpart) return hipErrorInvalidValue;
@@ -1827,8 +1984,15 @@ static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
             else return hipErrorInvalidValue;
             return hipGetLastError();
         } else if constexpr (E == EPI_SLAB && PBN == 3) {
-            if (g.cfg != 2 || !g.walk3) return hipErrorInvalidValue;
-            KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+            if (g.cfg != 2) return hipErrorInvalidValue;
+            if (g.walk3) {
+                if (g.slab_t) return hipErrorInvalidValue;
+                KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
+            } else {
+                // the plain byte-plane walk (ABP): one segment of three pieces, k slices of whole 128-deep blocks, no in-launch reduction
+                if (g.nseg != 1 || (int)((g.seg_codes >> 2) & 3u) != 3 || (g.kt_per_split & 1) || g.fuse || g.f8pos) return hipErrorInvalidValue;
+                KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true, true>), dim3(nblk), dim3(768), 0, st, g);
+            }
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;
@@ -1884,8 +2048,17 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
         }
     }
     // shared B staging: a three-piece A operand against three-piece weights, (piece p) x (pieces 0 .. 2 - p), one k slice
-    g.bshare = (epi == EPI_HALFSTEP && g.pb_max == 3 && !g.a_bytes && g.nseg == 3 && g.nsplit == 1 && g.seg_fastest &&
-                (g.seg_codes & 0x7FFFull) == ((0ull | (3ull << 2)) | ((1ull | (2ull << 2)) << 5) | ((2ull | (1ull << 2)) << 10))) ? 1 : 0;
+    {
+        const bool tri = g.pb_max == 3 && !g.a_bytes && g.nseg == 3 && g.seg_fastest && ((g.seg_codes >> 4) & 1ull) == ((g.seg_codes >> 9) & 1ull) &&
+                         ((g.seg_codes >> 4) & 1ull) == ((g.seg_codes >> 14) & 1ull) &&
+                         (g.seg_codes & 0x7FFFull & ~0x4210ull) == ((0ull | (3ull << 2)) | ((1ull | (2ull << 2)) << 5) | ((2ull | (1ull << 2)) << 10));
+        g.bshare = (epi == EPI_HALFSTEP && tri && g.nsplit == 1 && !((g.seg_codes >> 4) & 1ull)) ? 1 : 0;
+        // ... on 128 x 128 tiles the PAIRED walk (k_gemm_pb, "BSP"): two tiles per k position; also the statistics GEMM whose only
+        // segments are these three (the negative phase of Gaussian visibles), any number of k slices of whole positions
+        if (tri && g.pair_ok && g.cfg == 0 && (epi == EPI_HALFSTEP ? g.bshare == 1 : (epi == EPI_SLAB && !g.f8pos && !g.fuse)) &&
+            g.kt_per_split % 3 == 0 && g.kt_total % 3 == 0)
+            g.bshare = 2;
+    }
     // the statistics of real-valued data: positive segments (set 0, one B piece each) in front of the negative ones (set 1, the
     // first with three B pieces), segment-fastest, whole k positions per slice, no fp8 tiles
     g.bshare2 = 0; g.bsh_np = 0;

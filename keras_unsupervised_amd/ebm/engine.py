@@ -379,13 +379,15 @@ class DeviceRBM:
         comm.allreduce_sum_(delta)
         self.apply_delta(lr, compute=compute)
 
-    def cd_step_x3_stage(self, v, rows, row_start, lr, seed, step, stage):
-        """Measurement hook (bench.py): ONE launch of the x3 CD-1 sequence on the planes the previous
-        complete x3 step left in the workspace; stage numbering as kurbm_cd_step_x3_stage."""
+    def cd_step_x3_stage(self, v, rows, row_start, lr, seed, step, stage, mode=MODE_VISIBLE_BERNOULLI, planes=None):
+        """Measurement hook (bench.py, tools/stage_times.py): ONE launch of the x3 CD-1 sequence on the planes the previous
+        complete x3 step (same rows, data and mode) left in the workspace; stage numbering as kurbm_cd_step_x3_stage."""
         with torch.cuda.device(self.device):
-            vp = self._x3_pieces(v, None, MODE_VISIBLE_BERNOULLI)   # (as cd_step passes it: the planes must read the same)
+            vp = self._x3_pieces(v, None, mode)   # (as cd_step passes it: the planes must read the same)
             mir, ws = self.mirror(3), self.workspace_bf16(rows, 1, 3, vp)
-            opts = CdOpts(1, MODE_VISIBLE_BERNOULLI, float(lr), 1, None, None, int(seed), 0, int(step) & 0xFFFFFFFF, 0)
+            opts = CdOpts(1, int(mode), float(lr), 1, None, None, int(seed), 0, int(step) & 0xFFFFFFFF, 0)
+            if planes is not None:
+                opts.v_planes = planes.ptr(v, row_start, rows, vp)
             check(self.lib.kurbm_cd_step_x3_stage(self.ctx.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
                                                   v.ptr(row_start), vp, rows, v.ld, C.byref(opts), WHICH_ALL, int(stage),
                                                   ws.data_ptr(), ws.numel(), self._stream()))

@@ -1016,6 +1016,54 @@ def test_x3_transform_surface(gpu_device):
     assert np.max(np.abs(Va - Vb)) <= TOL
 
 
+@pytest.mark.parametrize("cfg", [dict(B=4096, nv=784, nh=1024, gauss=True), dict(B=4096, nv=784, nh=1024, gauss=False),
+                                 dict(B=300, nv=260, nh=136, gauss=True), dict(B=200, nv=300, nh=140, gauss=False),
+                                 dict(B=1024, nv=100, nh=1030, gauss=True)])
+def test_x3_real_valued_data_walks_agree(gpu_device, ctx_option, cfg):
+    """Real-valued data (grey levels: three bf16 pieces per value) on the x3 path, both modes.  Round 4 gave it two new walks --
+    the half steps on a three-piece batch as TWO tiles per k position on 128 x 128 tiles (KURBM_X3_PAIR), and the statistics as two
+    launches, the positive half as the transposed problem on a byte plane of h_pos^T (KURBM_X3_SPLIT_STATS).  Every combination of
+    the two knobs gives the same chain bit for bit (samples are (u < p) of probabilities that differ in the last ulps at most: the
+    test holds them to the oracle's tolerance) and statistics that agree with float64 statistics of the oracle's chain to the
+    1e-4 bar; the planes the step kept (h_pos^T as bytes, v_neg^T as bytes or pieces) decode to the chain's own states."""
+    from keras_unsupervised_amd import _lib
+    B, nv, nh = cfg["B"], cfg["nv"], cfg["nh"]
+    mode = O.MODE_VISIBLE_GAUSSIAN if cfg["gauss"] else O.MODE_VISIBLE_BERNOULLI
+    W, b_h, b_v = synthetic_params(nv, nh, seed=2500 + B)
+    v = (np.floor(synthetic_real(B, nv, seed=2501 + B) * 256.0) / 255.0).astype(np.float32)      # grey levels k / 255
+    _, _, _, ch, _ = O.cd_step_fused(W, b_h, b_v, v, 0.01, 31, 2, k=1, mode=mode)
+    got = {}
+    for pair in (1, 0):
+        for split in (1, 0):
+            ctx_option("KURBM_X3_PAIR", pair, 1)
+            ctx_option("KURBM_X3_SPLIT_STATS", split, 1)
+            e = _engine(W, b_h, b_v, gpu_device)
+            vd = _dm(v, gpu_device)
+            d = _gpu_cd_delta(e, vd, B, 0.01, 31, 2, mode=mode, compute="x3")
+            dW, dbh, dbv = _split(d, nv, nh)
+            hp = e.dump_plane(_lib.PLANE_H_POS, vd, B, mode).to_numpy()
+            hpT = e.dump_plane(_lib.PLANE_H_POS_T, vd, B, mode).to_numpy()
+            vn = e.dump_plane(_lib.PLANE_V_NEG, vd, B, mode).to_numpy()
+            vnT = e.dump_plane(_lib.PLANE_V_NEG_T, vd, B, mode).to_numpy()
+            hn = e.dump_plane(_lib.PLANE_H_NEG_T, vd, B, mode).to_numpy()
+            assert np.array_equal(hp, hpT) and np.array_equal(vn, vnT), (pair, split)
+            assert set(np.unique(hp)) <= {0.0, 1.0}
+            # the chain against the oracle's (a borderline draw -- |u - p| inside the rounding band -- may flip a unit)
+            assert np.mean(hp != ch["h_pos"]) < 1e-4
+            if np.array_equal(hp, ch["h_pos"]):
+                assert np.max(np.abs(vn - ch["v_neg"])) <= TOL if cfg["gauss"] else np.mean(vn != ch["v_neg"]) < 1e-4
+            # the statistics against float64 statistics of the chain this step ran (its own planes, decoded)
+            dW64, dbh64, dbv64 = O.cd_statistics(dict(v_pos=v.astype(np.float64), h_pos=hp.astype(np.float64), v_neg=vn.astype(np.float64),
+                                                      h_neg=hn.astype(np.float64)))
+            assert rel_err(dW, dW64) <= TOL and rel_err(dbh, dbh64) <= TOL and rel_err(dbv, dbv64) <= TOL, (pair, split)
+            got[(pair, split)] = (d, hp, vn)
+    # the chain does not depend on how the statistics are cut; the statistics agree to the order of their fp32 additions
+    for pair in (1, 0):
+        assert np.array_equal(got[(pair, 1)][1], got[(pair, 0)][1]) and np.array_equal(got[(pair, 1)][2], got[(pair, 0)][2])
+        assert rel_err(got[(pair, 1)][0], got[(pair, 0)][0]) <= 1e-5
+    assert np.mean(got[(1, 1)][1] != got[(0, 1)][1]) < 1e-4      # (paired / unpaired walks add the six piece products in another order)
+
+
 @pytest.mark.parametrize("cfg", [dict(B=30, nv=52, nh=44, k=1), dict(B=200, nv=300, nh=140, k=2),
                                  dict(B=130, nv=96, nh=260, k=1, pcd=True), dict(B=512, nv=784, nh=256, k=1)])
 def test_x3_gaussian_visibles_vs_oracle(gpu_device, cfg):

@@ -2,7 +2,7 @@
 """Phase lengths of the x3 GEMM launches of a config-2 CD-1 step (diagnostic build only):
 
     make -C keras_unsupervised_amd/csrc libkurbm_stamps.so
-    KURBM_LIB=keras_unsupervised_amd/csrc/libkurbm_stamps.so python tools/stamp_x3.py
+    KURBM_LIB=keras_unsupervised_amd/csrc/libkurbm_stamps.so python tools/stamp_x3.py [binary|grey] [bern|gauss]
 """
 import ctypes as C
 import os
@@ -20,7 +20,12 @@ B, NV, NH = 4096, 784, 1024
 dev = torch.device("cuda", 0)
 g = np.random.default_rng(1)
 eng = DeviceRBM(g.uniform(-0.05, 0.05, (NV, NH)).astype(np.float32), np.zeros(NH, np.float32), np.zeros(NV, np.float32), dev)
-V = DeviceMatrix.from_host((g.random((B, NV)) < 0.19).astype(np.float32), dev)
+kind = sys.argv[1] if len(sys.argv) > 1 else "binary"
+mode = 1 if (len(sys.argv) > 2 and sys.argv[2] == "gauss") else 0
+if kind == "binary":
+    V = DeviceMatrix.from_host((g.random((B, NV)) < 0.19).astype(np.float32), dev)
+else:
+    V = DeviceMatrix.from_host((np.floor(g.random((B, NV)) * 256.0) / 255.0).astype(np.float32), dev)
 lib = eng.lib
 lib.kurbm_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 lib.kurbm_debug_set_stamp_buffer.restype = None
@@ -42,7 +47,9 @@ def report(name, s):
           + " | tiles fp8 / 1 piece / 3 pieces: " + " ".join("%6.0f" % np.median(s[:, q]) for q in (6, 7, 14)))
 
 
-step = lambda: eng.cd_step(V, B, 0, 1e-3 / B, 42, 0, compute="x3")
+planes = eng.make_planes(V, [(0, B)], mode)
+step = lambda: eng.cd_step(V, B, 0, 1e-3 / B, 42, 0, mode=mode, compute="x3", planes=planes)
+print("data %s, mode %s" % (kind, "gauss" if mode else "bern"))
 for _ in range(3):
     step()
 torch.cuda.synchronize()
