@@ -148,7 +148,8 @@ def main():
 
     # BENCH_FORCE_DP=1 runs the data-parallel step (1-rank RCCL communicator) on a single-GPU box: a rehearsal of the N > 1 path
     use_dp = world > 1 or os.environ.get("BENCH_FORCE_DP", "0") == "1"
-    comm = dp.get_comm(device) if use_dp else None
+    # (KURBM_DP_EXCHANGE=peer: the two-shot exchange over hipIpc peer pointers, kurbm_peer_*, instead of RCCL's all-reduce)
+    comm = dp.get_exchange(device, N_VIS, N_HID) if use_dp else None
     rccl_ranks = comm.count() if comm is not None else None
     if comm is not None:
         assert rccl_ranks == world, "RCCL reports %d ranks, launched %d" % (rccl_ranks, world)
@@ -385,7 +386,10 @@ def main():
                        "compute": args.compute, "flop_per_step": FLOP_STEP,
                        "data_planes": None if planes is None else "resident: bf16 planes of the 16 batch windows made once before the warm-up "
                                       "(%.0f MB), as RBM.fit does once per call; paths.x3_convert_per_step converts the batch in every step" % (planes.buf.numel() / 1e6),
-                       "data_parallel_step": None if comm is None else "kurbm_cd_step_x3_dp (RCCL all-reduce inside libkurbm.so; row ranges: KURBM_DP_CHUNKS, default one)",
+                       "data_parallel_step": None if comm is None else (
+                           "kurbm_cd_step_x3_peer (two-shot all-reduce over hipIpc peer pointers, the apply fused into its second shot: KURBM_DP_EXCHANGE=peer)"
+                           if dp.exchange_kind() == "peer" else
+                           "kurbm_cd_step_x3_dp (RCCL all-reduce inside libkurbm.so; row ranges: KURBM_DP_CHUNKS, default one)"),
                        "timing": {"blocks": repeats, "steps_per_block": args.steps,
                                   "value": "N x K / median block time; W = %d untimed warm-up steps before the first block" % args.warmup,
                                   "value_first_block": "first block alone (cold clocks)",

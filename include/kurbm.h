@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define KURBM_ABI_VERSION 4
+#define KURBM_ABI_VERSION 5
 
 typedef struct kurbm_ctx kurbm_ctx;
 typedef struct kurbm_comm kurbm_comm; /* one RCCL communicator + the library's comm stream and events, per GPU */
@@ -396,6 +396,32 @@ int kurbm_cd_step_x3_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p,
 int kurbm_cd_step_bf16_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                           const float* v_batch, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks, void* workspace,
                           size_t workspace_bytes, kurbm_stream_t stream);
+
+/* ---- data parallel, plan B: the exchange through peer pointers, no collective library ----------------------------
+ *
+ * A two-shot all-reduce over hipIpc-mapped buffers, its second shot fused into the launch that applies the update
+ * (keras_unsupervised_amd/csrc/kurbm_peer.hip has the protocol).  Every rank: kurbm_peer_create (allocates and owns the
+ * rank's exchange buffer for an n_vis x n_hid RBM), kurbm_peer_handle (its hipIpc handle, kurbm_peer_handle_bytes() bytes --
+ * the host language carries the handles between the ranks, as it carries RCCL's unique id), kurbm_peer_connect with ALL
+ * ranks' handles in rank order (maps the peers' buffers).  Then kurbm_cd_step_x3_peer in lock step on all ranks: the same
+ * step as kurbm_cd_step_x3_dp with opts->apply = 1 (opts->delta_out is ignored: the sums live in the exchange buffers), sums
+ * added in rank order, so every replica ends with identical bits.  n_hid % 4 == 0; at most 8 ranks.  A rank that fails an
+ * argument check returns before it has published anything.  Every device-side wait is bounded (environment
+ * KURBM_PEER_TIMEOUT_MS, default 10 000): a peer that never arrives sets bit 1 of kurbm_ctx_status and the update is skipped.
+ * kurbm_peer_allreduce_sum_f32: the plain in-place sum of n <= n_vis n_hid + n_hid + n_vis floats (16-byte aligned), same protocol.
+ * RCCL (kurbm_comm_*) stays the default exchange; this one also runs between PROCESSES THAT SHARE ONE GPU, which RCCL refuses.
+ */
+typedef struct kurbm_peer kurbm_peer;
+size_t kurbm_peer_handle_bytes(void);
+int kurbm_peer_create(int device, int nranks, int rank, int n_vis, int n_hid, kurbm_peer** out);
+int kurbm_peer_handle(kurbm_peer* peer, void* handle, size_t handle_bytes);
+int kurbm_peer_connect(kurbm_peer* peer, const void* handles, size_t bytes);
+int kurbm_peer_ranks(const kurbm_peer* peer);
+int kurbm_peer_allreduce_sum_f32(kurbm_ctx* ctx, kurbm_peer* peer, float* buf, size_t n, kurbm_stream_t stream);
+int kurbm_cd_step_x3_peer(kurbm_ctx* ctx, kurbm_peer* peer, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                          const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, void* workspace,
+                          size_t workspace_bytes, kurbm_stream_t stream);
+void kurbm_peer_destroy(kurbm_peer* peer);
 
 /* *flag (device int, zeroed by the caller) |= 1 if some element of x [rows][ld] is not exactly representable in bf16,
  * |= 2 if some element is neither 0.0 nor 1.0.  0: v_pieces = 1 | KURBM_V_BINARY; 2: v_pieces = 1; else 3. */

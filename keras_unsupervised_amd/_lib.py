@@ -90,9 +90,17 @@ SIGNATURES = {
     "kurbm_allreduce_sum_f32": (_i, [_vp, _vp, _sz, _vp]),
     "kurbm_cd_step_x3_dp": (_i, [_vp, _vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _i, _vp, _sz, _vp]),
     "kurbm_cd_step_bf16_dp": (_i, [_vp, _vp, _PP, _vp, _sz, _vp, _i, _i, _OP, _i, _vp, _sz, _vp]),
+    "kurbm_peer_handle_bytes": (_sz, []),
+    "kurbm_peer_create": (_i, [_i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "kurbm_peer_handle": (_i, [_vp, _vp, _sz]),
+    "kurbm_peer_connect": (_i, [_vp, _vp, _sz]),
+    "kurbm_peer_ranks": (_i, [_vp]),
+    "kurbm_peer_allreduce_sum_f32": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "kurbm_cd_step_x3_peer": (_i, [_vp, _vp, _PP, _vp, _sz, _vp, _i, _i, _i, _OP, _vp, _sz, _vp]),
+    "kurbm_peer_destroy": (None, [_vp]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 V_BINARY = 0x10          # KURBM_V_BINARY: OR into v_pieces = 1 for 0/1 data
 PLANE_H_POS, PLANE_H_POS_T, PLANE_V_NEG, PLANE_V_NEG_T, PLANE_H_NEG_T = range(5)   # kurbm_x3_dump_plane
 UNIQUE_ID_BYTES = 128

@@ -81,6 +81,7 @@ static int fail(int code, const char* fmt, ...) {
 }
 
 namespace kurbm {
+unsigned* ctx_status_word(kurbm_ctx* ctx) { return ctx ? ctx->status : nullptr; }
 int fail_msg(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -918,7 +919,8 @@ static int check_cd_args(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_p
         return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
     if (v_pieces == (1 | KURBM_V_BINARY)) v_pieces = 1;
     if (v_pieces != 1 && v_pieces != 3) return fail(KURBM_ERR_ARG, "v_pieces must be 1, 1 | KURBM_V_BINARY or 3");
-    if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
+    // (a rank without rows of a remainder batch passes the clipped start of its empty shard: nothing is drawn for it)
+    if (rows > 0 && (o->row0 & 3)) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
     if (!mirror || !workspace || !aligned16(mirror) || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "mirror/workspace null or misaligned");
     if (o->v_chain && !aligned16(o->v_chain)) return fail(KURBM_ERR_ARG, "v_chain is misaligned");
     if (o->v_planes && !aligned16(o->v_planes)) return fail(KURBM_ERR_ARG, "v_planes is misaligned");
@@ -1541,6 +1543,44 @@ static int cd_step_dp_any(kurbm_ctx* ctx, kurbm_comm* comm, int pieces, const ku
         if (int e = kurbm_apply_delta(ctx, p, o.delta_out, o.lr, 7, stream)) return e;
         return mirror_refresh_any(ctx, pieces, p, mirror, mirror_bytes, stream);
     }
+    return KURBM_OK;
+}
+
+// The data-parallel x3 step on the PEER exchange (kurbm_peer.hip): chain -> statistics -> slab reduce into this rank's exported
+// `delta` region -> shot 1 (every rank sums its band of all ranks' deltas, in rank order) -> ONE launch that reads every band
+// from its owner's `sum` region and applies it (W, biases, both weight-piece mirrors).  Two launches beyond the local step's own.
+int kurbm_cd_step_x3_peer(kurbm_ctx* ctx, kurbm_peer* peer, const kurbm_params* p, void* mirror, size_t mirror_bytes,
+                          const float* v_batch, int v_pieces, int rows, int ldv, const kurbm_cd_opts* opts, void* workspace,
+                          size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx || !peer || !opts) return fail(KURBM_ERR_ARG, "null argument");
+    if (int e = check_params(p)) return e;
+    if (int e = peer_geometry_ok(peer, ctx->device, p->n_vis, p->n_hid)) return e;
+    if (!opts->apply) return fail(KURBM_ERR_ARG, "kurbm_cd_step_x3_peer applies the summed update in place: apply = 1");
+    if (rows < 0) return fail(KURBM_ERR_ARG, "rows must be >= 0");
+    // everything the step would refuse is refused HERE, before this rank publishes anything a peer waits for
+    if (int e = check_cd_args(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, opts, workspace, workspace_bytes, true)) return e;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t nw = (size_t)p->n_vis * p->n_hid, ntot = nw + p->n_hid + p->n_vis;
+    kurbm_cd_opts o = *opts;
+    o.apply = 0;
+    o.delta_out = peer_delta(peer);
+    if (rows == 0) HIP_TRY(hipMemsetAsync(o.delta_out, 0, ntot * sizeof(float), st));
+    else if (int e = cd_step_any(ctx, 3, v_pieces, p, mirror, mirror_bytes, v_batch, rows, ldv, &o, 7, workspace, workspace_bytes, stream)) return e;
+    PeerSrc src;
+    if (int e = peer_exchange_shot1(peer, ctx->status, st, &src)) return e;
+    // shot 2 = the apply: the packed total as ONE "slab" whose rows come from the band owners, one row of bias sums each
+    const Mirror m = carve_mirror(ctx, mirror, p->n_vis, p->n_hid, 3);
+    ReduceArgs a;
+    memset(&a, 0, sizeof a);
+    a.slab = src.own_sum; a.slab_stride = 0; a.nslab = 1; a.ld_slab = p->n_hid;
+    a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw; a.lr = o.lr;
+    a.W = p->W;
+    a.part_h = src.own_sum + nw; a.nrow_tiles_h = 1; a.ld_part_h = p->n_hid; a.b_h = p->b_h;
+    a.part_v = src.own_sum + nw + p->n_hid; a.nrow_tiles_v = 1; a.ld_part_v = p->n_vis; a.b_v = p->b_v;
+    a.Wb = m.Wb; a.ldWb = m.ldW; a.planeWb = m.planeW;
+    a.Wtb = m.Wtb; a.ldWtb = m.ldWt; a.planeWtb = m.planeWt; a.pieces = 3;
+    a.tile_rows = ctx->knob[KN_REDUCE_TR];
+    HIP_TRY(launch_reduce_apply_split(a, st, &src));
     return KURBM_OK;
 }
 

@@ -20,6 +20,7 @@
 // Reference op sequences: the same as the fp32 kernels (reference ku/ebm/rbm.py:46-47, :52-53,
 // :121-134); bf16 is an extension of this build, absent from the reference.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -120,12 +121,29 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
 // (and / or emit dW), then write the NEW weights as bf16 pieces row-major (8-byte stores) and, through an LDS transpose,
 // transposed; the k padding of both mirrors is rewritten as zeros.  Replaces k_reduce_apply + k_f32_to_bf16 on the fp32 master (one launch, one
 // pass over W instead of three).
-template <int TR>
-__global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int tiles_x, int tiles, int nbias) {
+// PEER (a template flag, so that the ordinary launch carries none of it): the summed statistics come from the ranks' exchange
+// buffers (kurbm_peer.hip) -- the rows of band q from rank q's `sum` region once its `summed` flag is up: the all-gather of the
+// two-shot all-reduce IS this launch's read.  Workgroup 0 also waits for EVERY rank's flag (a rank with an empty band still read
+// this rank's bias tail: nobody's `delta` may be rewritten before all are done).
+template <int TR, bool PEER = false>
+__global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int tiles_x, int tiles, int nbias, PeerSrc ps) {
     warm_kernel_arguments<sizeof(ReduceArgs) + 16>();   // (kurbm_device.h: one wait for the argument segment, not one per use)
     __shared__ __attribute__((aligned(16))) float tile[TR][CVT + 1];
+    [[maybe_unused]] __shared__ int peer_ok;
     const int t = threadIdx.x;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (PEER) {
+        if (blockIdx.x == 0) {
+            if (t == 0) peer_ok = 1;
+            __syncthreads();
+            if (t < ps.nranks && !wait_flag_ge(ps.summed[t], ps.epoch, ps.timeout_ticks)) peer_ok = 0;
+            __syncthreads();
+            if (!peer_ok) {
+                if (t == 0) __hip_atomic_fetch_or(ps.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+    }
     // the first nbias blocks: bias column sums (kurbm_kernels.h); then the tiles of W
     if ((int)blockIdx.x < nbias) {
         bias_colsum_wave(a, blockIdx.x * 4 + (t >> 6), t & 63);
@@ -134,6 +152,18 @@ __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int ti
     const int tb = (int)blockIdx.x - nbias;
     if (tb < tiles) {
         const int by = tb / tiles_x, bx = tb - by * tiles_x;
+        if constexpr (PEER) {
+            // the band of this tile's rows (band_rows is a multiple of TR; tiles past the matrix only write mirror padding)
+            int q = (by * TR) / ps.band_rows;
+            if (q >= ps.nranks) q = ps.nranks - 1;
+            if (t == 0) peer_ok = (by * TR >= a.n_vis || wait_flag_ge(ps.summed[q], ps.epoch, ps.timeout_ticks)) ? 1 : 0;
+            __syncthreads();
+            if (!peer_ok) {
+                if (t == 0) __hip_atomic_fetch_or(ps.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            a.slab = ps.sum[q];      // (nslab = 1, ld_slab = n_hid: the packed layout)
+        }
         const int q4 = (t & 15) * 4, rq = t >> 4;
         const int c = bx * CVT + q4;
         auto store3 = [&](uint16_t* dst, size_t plane, float v0, float v1, float v2, float v3) {
@@ -278,7 +308,7 @@ hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, ui
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st) {
+hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st, const PeerSrc* peer) {
     // the tile grid covers the padded extents of both mirrors (their zero k padding is written here)
     int r_ext = a.n_vis, c_ext = a.n_hid;
     if (a.Wb && a.ldWb > c_ext) c_ext = a.ldWb;
@@ -288,11 +318,21 @@ hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st) {
     // taller tiles = longer runs in the transposed mirror (2 TR bytes per column) but fewer workgroups
     const int forced = (a.tile_rows == 16 || a.tile_rows == 32 || a.tile_rows == 64) ? a.tile_rows : 0;
     int tr = forced ? forced : (tiles_x * ((r_ext + 31) / 32) >= 384 ? 32 : 16);
+    PeerSrc ps;
+    memset(&ps, 0, sizeof ps);
+    if (peer && peer->band_rows) {
+        ps = *peer;
+        if (tr > 32) tr = 32;                                   // (band boundaries are multiples of 32 rows)
+        if (ps.band_rows % 32 != 0 || nb < 1 || a.nslab != 1) return hipErrorInvalidValue;
+    }
     const int tiles_y = (r_ext + tr - 1) / tr;
     const dim3 grid(tiles_x * tiles_y + nb);
-    if (tr == 64) hipLaunchKernelGGL(k_reduce_apply_split<64>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb);
-    else if (tr == 32) hipLaunchKernelGGL(k_reduce_apply_split<32>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb);
-    else hipLaunchKernelGGL(k_reduce_apply_split<16>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb);
+    if (ps.band_rows) {
+        if (tr == 32) hipLaunchKernelGGL((k_reduce_apply_split<32, true>), grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
+        else hipLaunchKernelGGL((k_reduce_apply_split<16, true>), grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
+    } else if (tr == 64) hipLaunchKernelGGL(k_reduce_apply_split<64>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
+    else if (tr == 32) hipLaunchKernelGGL(k_reduce_apply_split<32>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
+    else hipLaunchKernelGGL(k_reduce_apply_split<16>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
     return hipGetLastError();
 }
 

@@ -132,6 +132,23 @@ __device__ __forceinline__ uint32_t bf16_piece_bits(float x, int j) {
 }
 
 
+// Bounded wait on a flag another agent writes (the peer exchange, kurbm_peer.hip): until *flag >= epoch, by system-scope acquire
+// loads -- the writer is another device, or another process on this one -- with the constant 100 MHz clock as the bound.  False on
+// a timeout: the caller reports through the context's status word and skips its work; nothing spins for ever.
+__device__ __forceinline__ unsigned long long realtime_ticks() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ inline bool wait_flag_ge(const unsigned* flag, unsigned epoch, unsigned long long timeout_ticks) {
+    const unsigned long long t0 = realtime_ticks();
+    for (;;) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch) return true;   // (epochs only grow: 2^32 steps)
+        __builtin_amdgcn_s_sleep(8);
+        if (realtime_ticks() - t0 > timeout_ticks) return false;
+    }
+}
+
 // Byte planes of 0/1 values (A operand of k_gemm_pb<..., AB>) are K-PERMUTED inside every group of 64 elements: element
 // 32 ks + 8 s + j (j < 8) of a group sits at byte 16 s + 8 ks + j, so that the bytes of both k-steps which lane group s of the
 // MFMA operand needs are 16 consecutive bytes.  c -> the position of column c in its row.

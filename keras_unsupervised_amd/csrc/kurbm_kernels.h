@@ -145,6 +145,21 @@ __device__ __forceinline__ void bias_colsum_wave(const ReduceArgs& a, int group,
 }
 #endif
 
+// The peer exchange (kurbm_peer.hip): where the reduce / apply launch reads the SUMMED packed statistics when they come from the
+// ranks' exchange buffers instead of slabs -- rows [q band_rows, (q + 1) band_rows) of dW from rank q's `sum` region, once that
+// rank's `summed` flag has reached `epoch` (bounded wait; a timeout sets bit 1 of *status and skips the tile).
+constexpr int PEER_MAX = 8;
+struct PeerSrc {
+    const float* sum[PEER_MAX];
+    const unsigned* summed[PEER_MAX];
+    const float* own_sum;              // this rank's own region: the bias tail, summed by every rank itself
+    unsigned* status;
+    unsigned long long timeout_ticks;  // of the 100 MHz constant clock
+    unsigned epoch;
+    int band_rows;                     // 0: no peer source (the ordinary launch)
+    int nranks;
+};
+
 struct ApplyArgs {
     const float* delta;
     float* W;
@@ -324,8 +339,18 @@ hipError_t launch_bf16_exact_check(const float* in, int rows, int cols, int ld_i
 hipError_t launch_gemm(int layout, int cfg, int epi, const GemmArgs& g, hipStream_t st);
 hipError_t launch_philox_uniform(float* out, int rows, int cols, int ld, const RngArgs& rng, hipStream_t st);
 hipError_t launch_reduce_apply(const ReduceArgs& a, hipStream_t st);
-hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st);
+hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st, const PeerSrc* peer = nullptr);
 hipError_t launch_apply_delta(const ApplyArgs& a, hipStream_t st);
 hipError_t launch_free_energy_finish(const FinishArgs& a, hipStream_t st);
 
+}  // namespace kurbm
+
+// kurbm_peer.hip <-> kurbm_api.hip
+struct kurbm_ctx;
+struct kurbm_peer;
+namespace kurbm {
+unsigned* ctx_status_word(kurbm_ctx* ctx);
+float* peer_delta(kurbm_peer* x);                                            // this rank's `delta` region: the step writes its packed sums here
+int peer_geometry_ok(const kurbm_peer* x, int device, int n_vis, int n_hid); // 0 or KURBM_ERR_* (message set)
+int peer_exchange_shot1(kurbm_peer* x, unsigned* status, hipStream_t st, PeerSrc* src);   // next epoch: sum the own band; fills `src` for shot 2
 }  // namespace kurbm

@@ -92,7 +92,85 @@ class Comm:
             self.handle = None
 
 
+class PeerExchange:
+    """The exchange through peer pointers (include/kurbm.h: kurbm_peer_*; keras_unsupervised_amd/csrc/kurbm_peer.hip): a two-shot
+    all-reduce over hipIpc-mapped buffers, the second shot fused into the launch that applies the update.  No collective library:
+    it also runs between processes that SHARE one GPU.  torch.distributed carries the 64-byte IPC handles, nothing else.
+    Duck-types Comm (count / allreduce_sum_ / barrier / destroy), so RBM.fit's data-parallel loop does not care which it has."""
+
+    def __init__(self, device, rank, world_size, n_vis, n_hid):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.rank, self.world_size, self.n_vis, self.n_hid = int(rank), int(world_size), int(n_vis), int(n_hid)
+        h = C.c_void_p()
+        _lib.check(self.lib.kurbm_peer_create(int(self.device.index), self.world_size, self.rank, self.n_vis, self.n_hid, C.byref(h)))
+        self.handle = h
+        nb = int(self.lib.kurbm_peer_handle_bytes())
+        buf = C.create_string_buffer(nb)
+        _lib.check(self.lib.kurbm_peer_handle(self.handle, buf, nb))
+        handles = [bytes(buf.raw)]
+        if self.world_size > 1:
+            handles = [None] * self.world_size
+            dist.all_gather_object(handles, bytes(buf.raw))
+            blob = b"".join(handles)
+            _lib.check(self.lib.kurbm_peer_connect(self.handle, C.create_string_buffer(blob, len(blob)), len(blob)))
+            dist.barrier()        # nobody starts a step before every rank has mapped every buffer
+        self.capacity = self.n_vis * self.n_hid + self.n_hid + self.n_vis
+
+    def count(self):
+        return int(self.lib.kurbm_peer_ranks(self.handle))
+
+    def allreduce_sum_(self, t):
+        """In-place sum over all ranks of a contiguous fp32 device tensor (in pieces of the exchange buffer's capacity)."""
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
+        ctx = _lib.Context.get(self.device.index)
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        flat = t.view(-1)
+        step = self.capacity // 4 * 4
+        for lo in range(0, flat.numel(), step):
+            n = min(step, flat.numel() - lo)
+            _lib.check(self.lib.kurbm_peer_allreduce_sum_f32(ctx.handle, self.handle, flat.data_ptr() + 4 * lo, n, st))
+        return t
+
+    def barrier(self):
+        if getattr(self, "_token", None) is None:
+            self._token = torch.zeros(4, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        self.allreduce_sum_(self._token)
+        torch.cuda.synchronize(self.device)
+
+    def destroy(self):
+        if self.handle:
+            self.lib.kurbm_peer_destroy(self.handle)
+            self.handle = None
+
+
+def exchange_kind():
+    """'rccl' (default: ncclAllReduce inside libkurbm.so) or 'peer' (KURBM_DP_EXCHANGE=peer: the two-shot exchange over hipIpc)."""
+    import os
+    kind = os.environ.get("KURBM_DP_EXCHANGE", "rccl").lower()
+    if kind not in ("rccl", "peer"):
+        raise ValueError("KURBM_DP_EXCHANGE must be 'rccl' or 'peer', got %r" % kind)
+    return kind
+
+
 _comms = {}
+_peers = {}
+
+
+def get_exchange(device, n_vis, n_hid):
+    """The exchange of this process for an n_vis x n_hid RBM on `device`: the RCCL communicator, or (KURBM_DP_EXCHANGE=peer) the
+    peer exchange of that shape, created on first use (collective)."""
+    if exchange_kind() == "rccl":
+        return get_comm(device)
+    device = torch.device(device)
+    key = (device, int(n_vis), int(n_hid))
+    x = _peers.get(key)
+    if x is None:
+        rank, n = world()
+        with torch.cuda.device(device):
+            x = _peers[key] = PeerExchange(device, rank, n, n_vis, n_hid)
+    return x
 
 
 def get_comm(device):
@@ -111,9 +189,10 @@ def get_comm(device):
 
 
 def destroy_comms():
-    for comm in _comms.values():
+    for comm in list(_comms.values()) + list(_peers.values()):
         comm.destroy()
     _comms.clear()
+    _peers.clear()
 
 
 def packed_size(n_vis, n_hid):

@@ -346,9 +346,26 @@ class DeviceRBM:
         is ONE library call (kurbm_cd_step_x3_dp / _bf16_dp): one all-reduce of the packed sums on the launch stream (n_chunks > 1
         or KURBM_DP_CHUNKS > 1 opts into row ranges of dW, range i all-reduced + applied on the library's comm stream under the
         statistics GEMM of range i + 1); the fp32-MFMA path runs emit -> kurbm_allreduce_sum_f32 -> apply."""
+        if hasattr(comm, "capacity") and compute == "x3":
+            # the peer exchange (dp.PeerExchange): chain, statistics, two-shot exchange with the apply fused into its second shot
+            with torch.cuda.device(self.device):
+                vp = self._x3_pieces(v, v_chain, mode)
+                mir, ws = self.mirror(3), self.workspace_bf16(max(rows, 1), k, 3, vp)
+                opts = CdOpts(int(k), int(mode), float(lr), 1, None, v_chain.ptr(v_chain_row) if v_chain is not None else None,
+                              int(seed), int(row0), int(step) & 0xFFFFFFFF, int(chain))
+                if planes is not None and rows > 0:
+                    opts.v_planes = planes.ptr(v, row_start, rows, vp)
+                check(self.lib.kurbm_cd_step_x3_peer(self.ctx.handle, comm.handle, C.byref(self.params), mir.data_ptr(), mir.numel(),
+                                                     v.ptr(row_start), vp, int(rows), v.ld, C.byref(opts), ws.data_ptr(), ws.numel(),
+                                                     self._stream()))
+            self._weights_written(kept=3)
+            self._mirrors[3][1] = False
+            if rows > 0:
+                self._chain_written(v_chain, mode)
+            return
         delta = self.delta_buffer()
         # n_chunks 0: the library's choice (by the size of the exchange; ctx knob KURBM_DP_CHUNKS overrides)
-        if compute in ("x3", "bf16"):
+        if compute in ("x3", "bf16") and not hasattr(comm, "capacity"):
             pieces = 3 if compute == "x3" else 1
             with torch.cuda.device(self.device):
                 vp = self._x3_pieces(v, v_chain, mode) if pieces == 3 else 1

@@ -391,7 +391,7 @@ class RBM(object):
             raise ValueError("data-parallel training supports update_mode='fused' only")
         d = self._dev
         s_lo, s_hi = self._shard(rows, rank, world)
-        d.cd_step_dp(dp.get_comm(d.device), Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,
+        d.cd_step_dp(dp.get_exchange(d.device, d.n_vis, d.n_hid), Vd, s_hi - s_lo, lo + s_lo, lr, self.seed, step, k=self.cd_k, mode=self.mode,
                      chain=CHAIN_W, row0=s_lo, v_chain=self._v_chain if self.persistent else None, v_chain_row=s_lo,
                      compute=self._compute(), planes=self._planes)
 
@@ -409,7 +409,7 @@ class RBM(object):
         with device_guard(self._dev.device):
             own = torch.zeros_like(self._v_chain.t)
             own[lo:hi].copy_(self._v_chain.t[lo:hi])
-            dp.get_comm(self._dev.device).allreduce_sum_(own.view(-1))
+            dp.get_exchange(self._dev.device, self._dev.n_vis, self._dev.n_hid).allreduce_sum_(own.view(-1))
             return own[: self._v_chain.rows, : self._v_chain.cols].contiguous().cpu().numpy()
 
     def _shard(self, rows, rank, world):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libkurbm.so does not export %s" % name
     assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
-    assert lib.kurbm_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.kurbm_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_header_is_plain_c_and_structs_match(tmp_path):
