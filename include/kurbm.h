@@ -397,6 +397,20 @@ int kurbm_cd_step_bf16_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* 
                           const float* v_batch, int rows, int ldv, const kurbm_cd_opts* opts, int n_chunks, void* workspace,
                           size_t workspace_bytes, kurbm_stream_t stream);
 
+/* ---- small RBMs: one launch per step -----------------------------------------------------------------------------
+ * The whole fused CD-1 update (rbm.py:120-134) of a SMALL problem -- the reference example's own 784 -> 128 at batch 128,
+ * BASELINE.json configs[0] -- in ONE grid-resident launch (phases separated by device-scope barriers; csrc/kurbm_small.hip):
+ * at these sizes the five launches of kurbm_cd_step are five launch latencies for a few microseconds of arithmetic.  Same
+ * arguments, workspace (kurbm_workspace_bytes) and Philox counters as kurbm_cd_step; CD-1 from the data only (opts->k = 1,
+ * no v_chain), applied in place (opts->apply = 1, no delta_out; `which` honoured).  Results agree with kurbm_cd_step to fp32
+ * rounding (another summation order), not bit for bit.  The grid must be resident (at most one workgroup per CU, an otherwise
+ * idle device); a barrier that times out sets bit 2 of kurbm_ctx_status and the update is skipped.  kurbm_cd_epoch_small: every
+ * batch of an epoch in one call (returns the number of steps). */
+int kurbm_cd_step_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, int rows, int ldv,
+                        const kurbm_cd_opts* opts, int which, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+int kurbm_cd_epoch_small(kurbm_ctx* ctx, const kurbm_params* p, const float* V, int n_rows, int ldv, int batch_size,
+                         const kurbm_cd_opts* opts, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+
 /* ---- data parallel, plan B: the exchange through peer pointers, no collective library ----------------------------
  *
  * A two-shot all-reduce over hipIpc-mapped buffers, its second shot fused into the launch that applies the update

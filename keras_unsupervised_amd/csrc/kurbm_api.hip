@@ -320,7 +320,7 @@ int kurbm_ctx_status(kurbm_ctx* ctx, int* bits) {
     if (!ctx || !bits) return fail(KURBM_ERR_ARG, "null argument");
     unsigned v = 0;
     HIP_TRY(hipMemcpy(&v, ctx->status, sizeof v, hipMemcpyDeviceToHost));      // (synchronises with the device)
-    if (v) HIP_TRY(hipMemset(ctx->status, 0, sizeof v));
+    if (v) HIP_TRY(hipMemset(ctx->status, 0, 256));      // (also re-arms the grid barrier of kurbm_cd_step_small: words 16, 17)
     *bits = (int)v;
     return KURBM_OK;
 }
@@ -482,6 +482,57 @@ int kurbm_cd_step(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, i
     a.delta_bv = o->delta_out ? o->delta_out + (size_t)p->n_vis * p->n_hid + p->n_hid : nullptr;
     HIP_TRY(launch_reduce_apply(a, st));
     return KURBM_OK;
+}
+
+// One CD-1 update of a small RBM in ONE launch (kurbm_small.hip).  Workspace as kurbm_cd_step (kurbm_workspace_bytes).
+int kurbm_cd_step_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o,
+                        int which, void* workspace, size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx || !o) return fail(KURBM_ERR_ARG, "null argument");
+    if (int e = check_params(p)) return e;
+    if (rows <= 0) return fail(KURBM_ERR_ARG, "rows must be positive");
+    if (bad_matrix(v_batch, ldv, p->n_vis)) return fail(KURBM_ERR_ARG, "v_batch: null, misaligned, ld %% 4 != 0 or ld < n_vis");
+    if (o->k != 1 || o->v_chain || !o->apply || o->delta_out)
+        return fail(KURBM_ERR_UNSUPPORTED, "kurbm_cd_step_small runs CD-1 from the data, applied in place (k = 1, no v_chain, apply = 1, no delta_out)");
+    if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN) return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
+    if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
+    if (!workspace || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "workspace is null or misaligned");
+    const Workspace w = carve(ctx, workspace, rows, p->n_vis, p->n_hid, 1);
+    if (w.bytes > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    SmallArgs a;
+    memset(&a, 0, sizeof a);
+    a.W = p->W; a.b_h = p->b_h; a.b_v = p->b_v; a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw;
+    a.v = v_batch; a.rows = rows; a.ldv = ldv;
+    a.h_pos = w.h_pos; a.h_neg = w.h_neg; a.v_neg = w.v_neg; a.ldh = w.ldh; a.ldn = w.ldv;
+    a.bar = ctx->status + 16; a.status = ctx->status;
+    a.timeout_ticks = 200000000ull;          // 2 s of the 100 MHz clock: only a grid that is not resident ever gets there
+    const uint32_t base = o->chain * 64u;
+    a.rng_h = make_rng(o->seed, o->row0, base + 0u, o->step);
+    a.rng_v = make_rng(o->seed, o->row0, base + 1u, o->step);
+    a.which = which; a.gauss = (o->mode == KURBM_MODE_VISIBLE_GAUSSIAN) ? 1 : 0; a.lr = o->lr;
+    // workgroups: enough for the widest phase (one 16 x 16 tile of a half step per workgroup, one tile of W per wave), never more
+    // than the CUs -- the grid must be resident, one workgroup per CU
+    const int tm = ceil_div(rows, 16), tv = ceil_div(p->n_vis, 16), th = ceil_div(p->n_hid, 16);
+    int nblk = tm * th > tm * tv ? tm * th : tm * tv;
+    const int stat = ceil_div(tv * th + tv + th, 4);
+    if (stat > nblk) nblk = stat;
+    if (nblk > ctx->ncu) nblk = ctx->ncu;
+    if (nblk > 1024) nblk = 1024;
+    HIP_TRY(launch_cd1_small(a, nblk, static_cast<hipStream_t>(stream)));
+    return KURBM_OK;
+}
+
+int kurbm_cd_epoch_small(kurbm_ctx* ctx, const kurbm_params* p, const float* V, int n_rows, int ldv, int batch_size,
+                         const kurbm_cd_opts* opts, void* workspace, size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx || !opts) return fail(KURBM_ERR_ARG, "null argument");
+    if (n_rows < 0 || batch_size <= 0) return fail(KURBM_ERR_ARG, "bad row count / batch size");
+    kurbm_cd_opts o = *opts;
+    int steps = 0;
+    for (int lo = 0; lo < n_rows; lo += batch_size, ++steps) {
+        const int rows = (n_rows - lo < batch_size) ? n_rows - lo : batch_size;
+        if (int e = kurbm_cd_step_small(ctx, p, V + (size_t)lo * ldv, rows, ldv, &o, 7, workspace, workspace_bytes, stream)) return e;
+        ++o.step;
+    }
+    return steps;
 }
 
 int kurbm_cd_epoch(kurbm_ctx* ctx, const kurbm_params* p, const float* V, int n_rows, int ldv, int batch_size,

@@ -345,6 +345,22 @@ hipError_t launch_free_energy_finish(const FinishArgs& a, hipStream_t st);
 
 }  // namespace kurbm
 
+// kurbm_small.hip: the whole CD-1 step of a small RBM in one launch
+namespace kurbm {
+struct SmallArgs {
+    float* W; float* b_h; float* b_v;
+    const float* v;
+    float* h_pos; float* v_neg; float* h_neg;     // workspace planes [rows][ldh] / [rows][ldn]
+    unsigned* bar;                                 // {arrival count, generation}: two words of the context's status block
+    unsigned* status;
+    unsigned long long timeout_ticks;              // of the 100 MHz constant clock
+    RngArgs rng_h, rng_v;                          // the counters of the h_pos and v_neg sampling sites
+    int n_vis, n_hid, ldw, rows, ldv, ldh, ldn;
+    int which, gauss;
+    float lr;
+};
+hipError_t launch_cd1_small(const SmallArgs& a, int nblk, hipStream_t st);
+}
 // kurbm_peer.hip <-> kurbm_api.hip
 struct kurbm_ctx;
 struct kurbm_peer;

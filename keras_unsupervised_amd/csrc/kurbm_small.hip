@@ -1,0 +1,209 @@
+// kurbm_small.hip -- one CD-1 update of a SMALL RBM in ONE launch (the reference example's own size: 784 -> 128, batch 128;
+// BASELINE.json configs[0]: 784 x 256, batch 64).
+//
+// At these sizes a step is ~0.1-0.3 GFLOP: the five launches of kurbm_cd_step cost five launch latencies (~75 us per step,
+// tools/bench_example_config.py) for ~3 us of arithmetic.  Here the whole step -- rbm.py:120-134 in the fused form: h_pos sample,
+// v_neg sample, h_neg probabilities, dW / db_h / db_v applied -- is one grid-resident kernel of four phases with a device-scope
+// barrier between them (sense-reversing: a wrapping arrival counter and a generation word in the context's status block; every
+// wait is bounded and reports through kurbm_ctx_status instead of hanging):
+//   1  h_pos = (u < act(v . W + b_h))            one 16 x 16 output tile per workgroup pass, its four waves split k
+//   2  v_neg = (u < sigmoid(h_pos . W^T + b_v))  or  loc + N(0, 1)   (Gaussian visibles: Box-Muller of two Philox planes)
+//   3  h_neg = sigmoid(v_neg . W + b_h)
+//   4  W += lr (v_pos^T h_pos - v_neg^T h_neg): one 16 x 16 tile of W per WAVE, k = the batch, applied from the accumulators (no
+//      slabs); the bias column sums by waves of their own, fixed order (bit-reproducible)
+// Products on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fma chains, like kurbm_kernels.hip), operands straight
+// from L2 -- the whole problem is a few MB -- with the same k-slot permutation trick: a lane's four consecutive k feed four
+// successive MFMAs.  Same Philox counters as every other path (include/kurbm.h), so the draws are the oracle's; the sums are
+// added in another order than kurbm_cd_step's, so the two paths agree to fp32 rounding, not bit for bit.
+// Scope: CD-1 from the data, no persistent chain, update applied in place (`which` honoured); anything else takes kurbm_cd_step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/kurbm.h"
+#include "kurbm_kernels.h"
+#include "kurbm_comm.h"
+#include "kurbm_device.h"
+
+namespace kurbm {
+
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// all workgroups of the grid have arrived (and their writes are visible device-wide); false after a timeout
+__device__ bool grid_barrier(const SmallArgs& a, unsigned& gen) {
+    __shared__ int ok;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // this workgroup's plane stores: written back past its XCD's L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ok = 1;
+        const unsigned arrived = __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) {
+            __hip_atomic_store(a.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.bar + 1, gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const unsigned long long t0 = realtime_ticks();
+            while (__hip_atomic_load(a.bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(2);
+                if (realtime_ticks() - t0 > a.timeout_ticks) { ok = 0; break; }
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // the other workgroups' stores, not this CU's stale lines
+    ++gen;
+    return ok != 0;
+}
+
+// One 16 x 16 tile of C = A . B over the k chunks [c0, c1) of 16 (stride cs): the lane (x = lane & 15, slot = lane >> 4) feeds
+// k = 16 c + 4 slot + e to MFMA e of a chunk -- A and B agree on that map, so any operand layout works:
+//   KC (k contiguous in memory):  one 16-byte load per chunk      X[x][k]  = base[x * ld + k]
+//   KS (k strided):               four 4-byte loads per chunk     X[k][x]  = base[k * ld + x]
+// x_ok / k < K guard ragged shapes (zeros contribute nothing).  NEG: the A values enter negated.
+// A and B point at the TILE (KC: its first row; KS: its first column), so x = lane & 15 indexes both.
+template <bool A_KC, bool B_KC, bool NEG>
+__device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A, int lda, bool a_ok, const float* __restrict__ B, int ldb, bool b_ok,
+                                         int K, int c0, int c1, int cs, int x, int slot) {
+    for (int c = c0; c < c1; c += cs) {
+        const int k = 16 * c + 4 * slot;
+        float av[4], bv[4];
+        if (A_KC) {
+            if (a_ok && k + 3 < K) { const f32x4 t = *reinterpret_cast<const f32x4*>(A + (size_t)x * lda + k); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
+            else for (int e = 0; e < 4; ++e) av[e] = (a_ok && k + e < K) ? A[(size_t)x * lda + k + e] : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = (a_ok && k + e < K) ? A[(size_t)(k + e) * lda + x] : 0.f;
+        }
+        if (B_KC) {
+            if (b_ok && k + 3 < K) { const f32x4 t = *reinterpret_cast<const f32x4*>(B + (size_t)x * ldb + k); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
+            else for (int e = 0; e < 4; ++e) bv[e] = (b_ok && k + e < K) ? B[(size_t)x * ldb + k + e] : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (b_ok && k + e < K) ? B[(size_t)(k + e) * ldb + x] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(NEG ? -av[e] : av[e], bv[e], acc, 0, 0, 0);
+    }
+}
+
+// A half step over all 16 x 16 tiles of out [rows][N]: a workgroup takes tiles blockIdx.x, + gridDim.x, ...; its four waves
+// split the k chunks and meet in LDS (added in wave order); wave 0 finishes the tile: bias, activation, draw, store.
+// HV = false: out = f(in . W + b_h) (k = visible units, W read as [k][n]); HV = true: out = f(in . W^T + b_v) (W read as [n][k]).
+template <bool HV>
+__device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in, int ld_in, float* __restrict__ out, int ldo, int act,
+                                int noise, const RngArgs& rng, float* red) {
+    const int K = HV ? a.n_hid : a.n_vis, N = HV ? a.n_vis : a.n_hid;
+    const float* bias = HV ? a.b_v : a.b_h;
+    const int tiles_m = (a.rows + 15) / 16, tiles_n = (N + 15) / 16, nch = (K + 15) / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, slot = lane >> 4;
+    for (int t = blockIdx.x; t < tiles_m * tiles_n; t += gridDim.x) {
+        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+        const int m = tm * 16 + x, n = tn * 16 + x;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* At = in + (size_t)tm * 16 * ld_in;                                      // rows of the batch, k contiguous
+        if (HV) tile_mma<true, true, false>(acc, At, ld_in, m < a.rows, a.W + (size_t)tn * 16 * a.ldw, a.ldw, n < N, K, wave, nch, 4, x, slot);   // W^T: rows = visible units
+        else    tile_mma<true, false, false>(acc, At, ld_in, m < a.rows, a.W + tn * 16, a.ldw, n < N, K, wave, nch, 4, x, slot);                 // W as [k][n]
+        *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc;
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 s = *reinterpret_cast<const f32x4*>(red + lane * 4);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) s += *reinterpret_cast<const f32x4*>(red + (q * 64 + lane) * 4);
+            const int col = tn * 16 + x, row0 = tm * 16 + 4 * slot;     // C layout: lane holds rows row0 .. row0 + 3 of column col
+            if (col < N) {
+                const float b = bias[col];
+                uint32_t w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
+                const uint64_t grow = rng.row0 + (uint64_t)row0;
+                if (noise != NOISE_NONE) philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), rng.stream_id, rng.step, rng.seed_lo, rng.seed_hi, w1);
+                if (noise == NOISE_GAUSSIAN)
+                    philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), rng.stream_id | 0x80000000u, rng.step, rng.seed_lo, rng.seed_hi, w2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xv = s[r] + b;
+                    const float p = act == ACT_SIGMOID ? sigmoidf_fast(xv) : (act == ACT_RELU ? fmaxf(xv, 0.f) : xv);
+                    float y = p;
+                    if (noise == NOISE_BERNOULLI) y = (u32_to_unit(w1[r]) < p) ? 1.f : 0.f;
+                    else if (noise == NOISE_GAUSSIAN) y = p + box_muller(u32_to_unit(w1[r]), u32_to_unit(w2[r]));
+                    if (row0 + r < a.rows) out[(size_t)(row0 + r) * ldo + col] = y;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+    unsigned gen = 0;
+    if (threadIdx.x == 0) gen = __hip_atomic_load(a.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gen = __builtin_amdgcn_readfirstlane(gen);   // (only thread 0 uses it; uniform for tidiness)
+    const int act_h = a.gauss ? ACT_RELU : ACT_SIGMOID, act_v = a.gauss ? ACT_LINEAR : ACT_SIGMOID;
+    bool ok = true;
+    // 1: h_pos ~ p(h | v_pos)                                                   rbm.py:120
+    half_step_small<false>(a, a.v, a.ldv, a.h_pos, a.ldh, act_h, NOISE_BERNOULLI, a.rng_h, red);
+    ok = grid_barrier(a, gen) && ok;
+    // 2: v_neg ~ p(v | h_pos)                                                   rbm.py:121-123 / :143-144
+    if (ok) half_step_small<true>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red);
+    ok = grid_barrier(a, gen) && ok;
+    // 3: h_neg = sigmoid(v_neg . W + b_h): probabilities in both modes          rbm.py:124 / :145
+    if (ok) half_step_small<false>(a, a.v_neg, a.ldn, a.h_neg, a.ldh, ACT_SIGMOID, NOISE_NONE, a.rng_h, red);
+    ok = grid_barrier(a, gen) && ok;
+    if (!ok) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // 4: the statistics, applied.  Tasks, one per wave: the 16 x 16 tiles of W, then 16-column groups of db_h and db_v
+    const int lane = threadIdx.x & 63, x = lane & 15, slot = lane >> 4;
+    const int tiles_v = (a.n_vis + 15) / 16, tiles_h = (a.n_hid + 15) / 16, nch = (a.rows + 15) / 16;
+    const int n_w = (a.which & 1) ? tiles_v * tiles_h : 0, n_bh = (a.which & 2) ? tiles_h : 0, n_bv = (a.which & 4) ? tiles_v : 0;
+    const int nwaves = gridDim.x * 4;
+    for (int task = blockIdx.x * 4 + (threadIdx.x >> 6); task < n_w + n_bh + n_bv; task += nwaves) {
+        if (task < n_w) {
+            const int ti = task / tiles_h, tj = task - ti * tiles_h;
+            const int i = ti * 16 + x, j = tj * 16 + x;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // dW = v_pos^T . h_pos - v_neg^T . h_neg   (rbm.py:125-126), k = the batch rows: both operands k-strided
+            tile_mma<false, false, false>(acc, a.v + ti * 16, a.ldv, i < a.n_vis, a.h_pos + tj * 16, a.ldh, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+            tile_mma<false, false, true>(acc, a.v_neg + ti * 16, a.ldn, i < a.n_vis, a.h_neg + tj * 16, a.ldh, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+            const int col = tj * 16 + x, row0 = ti * 16 + 4 * slot;
+            if (col < a.n_hid)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < a.n_vis) a.W[(size_t)(row0 + r) * a.ldw + col] += a.lr * acc[r];      // rbm.py:127-128
+        } else {
+            // a bias group: lane (column x, row group slot) adds rows slot, slot + 4, ... (eight loads in flight), then the four
+            // row groups meet by shuffles, ((g0 + g1) + (g2 + g3)): a fixed order
+            const bool hid = task < n_w + n_bh;
+            const int g = hid ? task - n_w : task - n_w - n_bh;
+            const int col = g * 16 + x, N = hid ? a.n_hid : a.n_vis;
+            const float* pos = hid ? a.h_pos : a.v;
+            const float* neg = hid ? a.h_neg : a.v_neg;
+            const int ldp = hid ? a.ldh : a.ldv, ldq = hid ? a.ldh : a.ldn;
+            float s = 0.f;
+            if (col < N)
+                for (int r0 = slot; r0 < a.rows; r0 += 32) {
+                    float d[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = r0 + 4 * e;
+                        d[e] = r < a.rows ? pos[(size_t)r * ldp + col] - neg[(size_t)r * ldq + col] : 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s += d[e];
+                }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (slot == 0 && col < N) {
+                float* b = hid ? a.b_h : a.b_v;
+                b[col] += a.lr * s;                                                                    // rbm.py:130-134
+            }
+        }
+    }
+}
+
+hipError_t launch_cd1_small(const SmallArgs& a, int nblk, hipStream_t st) {
+    hipLaunchKernelGGL(k_cd1_small, dim3(nblk), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace kurbm

@@ -334,8 +334,15 @@ class DeviceRBM:
                                              C.byref(opts), int(which), ws.data_ptr(), ws.numel(), self._stream()))
                 if apply and (which & 1):
                     self._weights_written()
+            elif compute == "small":
+                # the whole CD-1 step in one launch (kurbm_small.hip): small problems, where the step is launch latencies
+                ws = self.workspace(rows, k)
+                check(self.lib.kurbm_cd_step_small(self.ctx.handle, C.byref(self.params), v.ptr(row_start), rows, v.ld,
+                                                   C.byref(opts), int(which), ws.data_ptr(), ws.numel(), self._stream()))
+                if which & 1:
+                    self._weights_written()
             else:
-                raise ValueError("compute must be 'fp32', 'x3' or 'bf16', got %r" % (compute,))
+                raise ValueError("compute must be 'fp32', 'x3', 'bf16' or 'small', got %r" % (compute,))
         self._chain_written(v_chain, mode)
 
     def cd_step_dp(self, comm, v, rows, row_start, lr, seed, step, k=1, mode=MODE_VISIBLE_BERNOULLI, chain=0, row0=0,
@@ -435,7 +442,8 @@ class DeviceRBM:
             ws = self.workspace(min(batch_size, max(n_rows, 1)), k)
             opts = CdOpts(int(k), int(mode), float(lr), 1, None, v_chain.ptr() if v_chain is not None else None,
                           int(seed), 0, int(step0) & 0xFFFFFFFF, 0)
-            n = self.lib.kurbm_cd_epoch(self.ctx.handle, C.byref(self.params), v.ptr(row_start), int(n_rows), v.ld,
+            fn = self.lib.kurbm_cd_epoch_small if compute == "small" else self.lib.kurbm_cd_epoch
+            n = fn(self.ctx.handle, C.byref(self.params), v.ptr(row_start), int(n_rows), v.ld,
                                         int(batch_size), C.byref(opts), ws.data_ptr(), ws.numel(), self._stream())
             if n < 0:
                 check(n)

@@ -94,11 +94,13 @@ class RBM(object):
         # how the matrix products of fit() run (extension; storage, accumulation and results are fp32 in all):
         #   'fp32'  fp32 MFMA               'x3'  fp32 values as exact bf16 triples on the bf16 MFMA
         #   'bf16'  operands ROUNDED to bf16 (reduced precision, BASELINE.json config 5)
-        #   'auto'  (default) 'x3' at batch sizes >= 256, else 'fp32' (tools/bench_fit.py, 784 x 1024, us per step fp32 / x3,
-        #           end of round 3: batch 256 95 / 87, 512 102 / 87, 1024 122 / 95, 2048 194 / 105, 4096 341 / 129)
+        #   'small' the whole CD-1 step in ONE launch (kurbm_cd_step_small; fp32 MFMA): the reference example's own sizes
+        #   'auto'  (default) 'x3' at batch sizes >= 256 (tools/bench_fit.py, 784 x 1024, us per step fp32 / x3,
+        #           end of round 3: batch 256 95 / 87, 512 102 / 87, 1024 122 / 95, 2048 194 / 105, 4096 341 / 129); below that
+        #           'small' where it applies (CD-1 from the data, one GPU), else 'fp32' 
         self.compute_dtype = str(opt("compute_dtype", "auto"))
-        if self.compute_dtype not in ("fp32", "x3", "bf16", "auto"):
-            raise ValueError("compute_dtype must be 'fp32', 'x3', 'bf16' or 'auto'")
+        if self.compute_dtype not in ("fp32", "x3", "bf16", "small", "auto"):
+            raise ValueError("compute_dtype must be 'fp32', 'x3', 'bf16', 'small' or 'auto'")
         self.list_returns = bool(kwargs.pop("ku_compat_list_returns", True))
         self._device_arg = kwargs.pop("device", None)
         self._init_weights = kwargs.pop("weights", None)
@@ -332,7 +334,7 @@ class RBM(object):
         self._planes = planes
         # quiet single-GPU fused training (fp32 MFMA or x3): the whole batch loop of an epoch is one library call
         whole_epochs = (verbose != 1 and world == 1 and self.update_mode == "fused"
-                        and self._compute() in ("fp32", "x3"))
+                        and self._compute() in ("fp32", "x3", "small"))
         def print_score(score, label):
             self.last_scores.append(score)
             print("\n{0:d}/{1:d}, score: {2:f}".format(label[0], label[1], score))   # rbm.py:234
@@ -368,9 +370,12 @@ class RBM(object):
         return None
 
     def _compute(self):
-        if self.compute_dtype == "auto":
-            return "x3" if int(self.hps["batch_size"]) >= 256 else "fp32"
-        return self.compute_dtype
+        c = self.compute_dtype
+        if c == "auto":
+            c = "x3" if int(self.hps["batch_size"]) >= 256 else "small"
+        if c == "small" and (self.cd_k != 1 or self.persistent or dp.world()[1] > 1):
+            c = "fp32"        # the one-launch step is CD-1 from the data on one GPU; everything else takes the five-launch path
+        return c
 
     def _update_local(self, Vd, lo, rows, lr, step):
         d = self._dev

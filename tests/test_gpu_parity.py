@@ -228,6 +228,64 @@ def test_cd_step_config1_golden(gpu_device, golden_dir):
     assert np.array_equal(dbv, g["dbv"])
 
 
+def test_small_step_config1_golden(gpu_device, golden_dir):
+    """kurbm_cd_step_small -- the whole CD-1 update in ONE launch (csrc/kurbm_small.hip) -- at BASELINE config 1's shape against the
+    golden statistics: the applied update (W_new - W) / lr is the golden dW (fp32 rounding of W_new: ~4e-6 of an lr-sized step)."""
+    W, b_h, b_v = synthetic_params(784, 256, seed=11)
+    v = synthetic_binary(64, 784, seed=12)
+    g = np.load(os.path.join(golden_dir, "cd_step_config1.npz"))
+    e = _engine(W, b_h, b_v, gpu_device)
+    e.cd_step(_dm(v, gpu_device), 64, 0, 1e-3, 42, 0, compute="small")
+    Wn, bhn, bvn = e.get_weights()
+    assert rel_err((Wn - W)[::49, ::16] / 1e-3, g["dW_sub"]) <= TOL
+    assert rel_err((bhn - b_h) / 1e-3, g["dbh"]) <= TOL and rel_err((bvn - b_v) / 1e-3, g["dbv"]) <= TOL
+
+
+@pytest.mark.parametrize("cfg", [dict(B=64, nv=784, nh=256), dict(B=128, nv=784, nh=128), dict(B=16, nv=784, nh=128), dict(B=50, nv=70, nh=90),
+                                 dict(B=37, nv=100, nh=33, gauss=True), dict(B=128, nv=784, nh=128, gauss=True), dict(B=200, nv=300, nh=520)])
+def test_small_step_vs_oracle(gpu_device, cfg):
+    """The one-launch step against the oracle's fused CD-1 step (same Philox counters: the draws are the oracle's), the parameters
+    after TWO steps at the 1e-4 bar (the second step runs on the first one's weights and on the barrier state it left); ragged
+    shapes, Gaussian visibles; `which` restricts the update as kurbm_cd_step's does; the epoch call is its step loop, bit for bit;
+    and the five-launch fp32 path gives the same parameters to fp32 rounding."""
+    B, nv, nh = cfg["B"], cfg["nv"], cfg["nh"]
+    mode = O.MODE_VISIBLE_GAUSSIAN if cfg.get("gauss") else O.MODE_VISIBLE_BERNOULLI
+    W, b_h, b_v = synthetic_params(nv, nh, seed=2600 + B)
+    v = synthetic_real(2 * B, nv, seed=2601 + B) if cfg.get("gauss") else synthetic_binary(2 * B, nv, seed=2601 + B, p=0.3)
+    lr = 1e-3
+    ref = (W, b_h, b_v)
+    for step in range(2):
+        Wr, bhr, bvr, _, _ = O.cd_step_fused(*ref, v[step * B:(step + 1) * B], lr, 9, step, mode=mode)
+        ref = (Wr, bhr, bvr)
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(v, gpu_device)
+    for step in range(2):
+        e.cd_step(vd, B, step * B, lr, 9, step, mode=mode, compute="small")
+    got = e.get_weights()
+    for a, b in zip(got, ref):
+        assert np.max(np.abs(a - b)) <= TOL
+    e5 = _engine(W, b_h, b_v, gpu_device)
+    for step in range(2):
+        e5.cd_step(vd, B, step * B, lr, 9, step, mode=mode, compute="fp32")
+    for a, b in zip(got, e5.get_weights()):
+        assert np.max(np.abs(a - b)) <= 1e-5
+    # one call for the epoch = the step loop
+    e2 = _engine(W, b_h, b_v, gpu_device)
+    assert e2.cd_epoch(vd, 2 * B, B, lr, 9, 0, mode=mode, compute="small") == 2
+    for a, b in zip(got, e2.get_weights()):
+        assert np.array_equal(a, b)
+    # `which`: only the named parameters move, and they move as in the full step's first update
+    from keras_unsupervised_amd import _lib
+    full = _engine(W, b_h, b_v, gpu_device)
+    full.cd_step(vd, B, 0, lr, 9, 0, mode=mode, compute="small")
+    for which, idx in ((_lib.WHICH_W, 0), (_lib.WHICH_BH, 1), (_lib.WHICH_BV, 2)):
+        ew = _engine(W, b_h, b_v, gpu_device)
+        ew.cd_step(vd, B, 0, lr, 9, 0, mode=mode, which=which, compute="small")
+        for j, (a, b0, f) in enumerate(zip(ew.get_weights(), (W, b_h, b_v), full.get_weights())):
+            assert np.array_equal(a, f if j == idx else b0), (which, j)
+    e.check_status()
+
+
 @pytest.mark.parametrize("cfg", [dict(B=50, nv=70, nh=90, k=1), dict(B=133, nv=200, nh=120, k=3),
                                  dict(B=64, nv=784, nh=256, k=1), dict(B=40, nv=48, nh=64, k=2, pcd=True),
                                  dict(B=30, nv=52, nh=44, k=1, gauss=True)])
@@ -444,7 +502,7 @@ def test_c_abi_from_plain_c(gpu_device, tmp_path):
                     "-lm", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 4" in r.stdout
+    assert "abi 5" in r.stdout
 
 
 def test_c_abi_error_behaviour(gpu_device):
