@@ -642,6 +642,13 @@ int kurbm_outer_partial(kurbm_ctx* ctx, const float* v_pos, const float* h_pos, 
                        static_cast<hipStream_t>(stream));
 }
 
+#ifdef KURBM_SMALL_STAMPS
+/* diagnostic build only: the eight phase stamps of the last kurbm_cd_step_small (100 MHz ticks) */
+int kurbm_debug_small_stamps(kurbm_ctx* ctx, unsigned long long* out8) {
+    HIP_TRY(hipMemcpy(out8, ctx->status + 40, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return KURBM_OK;
+}
+#endif
 #ifdef KURBM_STAMPS
 /* diagnostic library only: not part of include/kurbm.h */
 void kurbm_debug_set_stamp_buffer(void* p) { set_stamp_buffer(static_cast<unsigned long long*>(p)); }
@@ -1390,7 +1397,8 @@ int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t m
     {
         HalfOutB ho;
         ho.out = w.v2b; ho.ldo = w.Lv; ho.out_pieces = vn_pieces; ho.out_plane = w.planeV; ho.out_bytes = nbytes;
-        ho.out_f32 = w.tmp32; ho.ldo32 = w.ldv32;
+        // (a 0/1 reconstruction: the score kernel takes v'.b_v from the byte plane; real-valued v' also leaves as fp32)
+        if (!nbytes) { ho.out_f32 = w.tmp32; ho.ldo32 = w.ldv32; }
         if ((e = half_step_b(ctx, LAYOUT_HV, p, m, w.hb, w.Lh, 1, 0, rows, gauss ? ACT_LINEAR : ACT_SIGMOID,
                              gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, &r, ho, st, hbytes))) return e;   // v'
     }
@@ -1402,6 +1410,9 @@ int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t m
         if ((e = half_step_b(ctx, LAYOUT_VH, p, m, w.v2b, w.Lv, vn_pieces, w.planeV, rows, ACT_SIGMOID, NOISE_NONE, nullptr, ho, st, nbytes))) return e;
     }
     ScoreArgs a;
+    memset(&a, 0, sizeof a);
+    if (nbytes) { a.v1b = reinterpret_cast<const unsigned char*>(w.v2b); a.ldv1b = w.Lv; }
+    a.counter = ctx->status + 32;
     a.v = v_batch; a.v1 = w.tmp32; a.b_v = p->b_v; a.rowpart = rp0; a.rowpart1 = rp1; a.F = F; a.absdiff = absdiff; a.score = score;
     a.rows = rows; a.n_vis = p->n_vis; a.ldv = ldv; a.ldv1 = w.ldv32; a.ncol_tiles = ncol0; a.ncol_tiles1 = ncol1; a.ld_rowpart = ld_rp;
     HIP_TRY(launch_score(a, st));                                                                      // mean |F - F'|  rbm.py:233

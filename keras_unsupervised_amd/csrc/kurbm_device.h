@@ -118,6 +118,17 @@ __device__ __forceinline__ float pair_swap(float v) {
 }
 
 
+// Sum over the 16 lanes of a DPP row (the lanes that share lane >> 4), the total in every lane: four DPP adds on the vector ALU.
+// (As __shfl_xor chains -- ds_bpermute through the LDS crossbar, four dependent ones per sum, sixteen sums per lane -- the row sums of
+//  a softplus epilogue took ~8 000 cycles of a half step: stamps of the score's GEMMs, round 4.)
+__device__ __forceinline__ float row16_sum(float t) {
+    t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x124, 0xF, 0xF, true));   // row_ror:4
+    t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x128, 0xF, 0xF, true));   // row_ror:8
+    return t;
+}
+
 // Exact three-way split of an fp32 value into bf16 pieces, x == hi + mid + lo (round to nearest even at
 // every stage: the two residuals are exact in fp32 and the last one has at most 8 significant bits).
 // piece j of x, j = 0, 1, 2:

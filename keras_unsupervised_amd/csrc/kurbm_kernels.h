@@ -173,7 +173,10 @@ struct ApplyArgs {
 // mean |F(v) - F(v')| into ONE device float (k_score_rows, k_score_mean: kurbm_kernels.hip)
 struct ScoreArgs {
     const float* v;        // [rows][ldv]  the batch
-    const float* v1;       // [rows][ldv1] its one-step reconstruction v' (fp32 plane)
+    const float* v1;       // [rows][ldv1] its one-step reconstruction v' (fp32 plane), or:
+    const unsigned char* v1b;   // v' as a byte plane of 0/1 values (0x40 = one, k-permuted: kperm64), ldv1b bytes per row; then v1 is unused
+    int ldv1b;
+    unsigned* counter;     // arrival counter of the launch (zero between launches: the last workgroup resets it)
     const float* b_v;
     const float* rowpart;  // [ncol_tiles][ld_rowpart] of v
     const float* rowpart1; // ... of v'

@@ -42,6 +42,8 @@
 
 namespace kurbm {
 
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+
 // Diagnostic build only (-DKURBM_STAMPS, libkurbm_stamps.so): s_memtime brackets around the
 // prologue / k loop / epilogue and the 8 MFMA groups of a tile, written to GemmArgs::stamps (16 x u64 per wave).  The shipped library has no stamps.
 #ifdef KURBM_STAMPS
@@ -573,11 +575,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float t = rsum[mi][r];
-                t += __shfl_xor(t, 1);
-                t += __shfl_xor(t, 2);
-                t += __shfl_xor(t, 4);
-                t += __shfl_xor(t, 8);
+                const float t = row16_sum(rsum[mi][r]);       // (kurbm_device.h: DPP adds, not ds_bpermute chains)
                 if (l15 == 0) smem[wn * BM + wm * WM + mi * 16 + slot * 4 + r] = t;
             }
         __syncthreads();
@@ -731,46 +729,74 @@ __global__ __launch_bounds__(256) void k_free_energy_finish(FinishArgs a) {
 __global__ __launch_bounds__(256) void k_score_rows(ScoreArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
-    if (row >= a.rows) return;
-    // v.b_v and v'.b_v: 16-byte loads, all of a row's in flight at once (rows are 16-byte aligned, ld % 4 == 0)
-    const int n4 = a.n_vis >> 2;
-    const float* vr = a.v + (size_t)row * a.ldv;
-    const float* v1r = a.v1 + (size_t)row * a.ldv1;
-    float t = 0.f, t1 = 0.f;
-    for (int c0 = 0; c0 < n4; c0 += 256) {
-        f32x4 x[4], y[4], b[4];
+    if (row < a.rows) {
+        // v.b_v and v'.b_v: 16-byte loads, all of a row's in flight at once (rows are 16-byte aligned, ld % 4 == 0)
+        const int n4 = a.n_vis >> 2;
+        const float* vr = a.v + (size_t)row * a.ldv;
+        float t = 0.f, t1 = 0.f;
+        if (a.v1b) {
+            // v' as the BYTE plane the half step left for the next GEMM (0x40 = one, k-permuted in groups of 64: kurbm_device.h
+            // kperm64): lane l takes bytes [16 l, 16 l + 16) of the row = columns g + 8 s + 0..7 and g + 32 + 8 s + 0..7
+            // (g = 64 (l / 4), s = l % 4) -- no fp32 copy of v' is written or read for a 0/1 reconstruction
+            const unsigned char* br = a.v1b + (size_t)row * a.ldv1b;
+            for (int q0 = 16 * lane; q0 < a.ldv1b; q0 += 16 * 64) {
+                const u32x4s w = *reinterpret_cast<const u32x4s*>(br + q0);
+                const int g = q0 & ~63, s8 = ((q0 >> 4) & 3) * 8;
+                const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c0 + e * 64 + lane;
-            const bool ok = c < n4;
-            x[e] = ok ? *reinterpret_cast<const f32x4*>(vr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            y[e] = ok ? *reinterpret_cast<const f32x4*>(v1r + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            b[e] = ok ? *reinterpret_cast<const f32x4*>(a.b_v + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 16; ++j) {
+                    const int c = g + s8 + (j & 7) + ((j >> 3) << 5);
+                    if (((wd[j >> 2] >> (8 * (j & 3))) & 0xFFu) && c < a.n_vis) t1 += a.b_v[c];
+                }
+            }
+            for (int c0 = 0; c0 < n4; c0 += 64) {
+                const int c = c0 + lane;
+                if (c < n4) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(vr + 4 * c), b = *reinterpret_cast<const f32x4*>(a.b_v + 4 * c);
+                    t += x.x * b.x + x.y * b.y + x.z * b.z + x.w * b.w;
+                }
+            }
+            for (int c = 4 * n4 + lane; c < a.n_vis; c += 64) t += vr[c] * a.b_v[c];
+        } else {
+            const float* v1r = a.v1 + (size_t)row * a.ldv1;
+            for (int c0 = 0; c0 < n4; c0 += 256) {
+                f32x4 x[4], y[4], b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + e * 64 + lane;
+                    const bool ok = c < n4;
+                    x[e] = ok ? *reinterpret_cast<const f32x4*>(vr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    y[e] = ok ? *reinterpret_cast<const f32x4*>(v1r + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    b[e] = ok ? *reinterpret_cast<const f32x4*>(a.b_v + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    t += x[e].x * b[e].x + x[e].y * b[e].y + x[e].z * b[e].z + x[e].w * b[e].w;
+                    t1 += y[e].x * b[e].x + y[e].y * b[e].y + y[e].z * b[e].z + y[e].w * b[e].w;
+                }
+            }
+            for (int c = 4 * n4 + lane; c < a.n_vis; c += 64) {      // (n_vis % 4 columns)
+                const float b = a.b_v[c];
+                t += vr[c] * b;
+                t1 += v1r[c] * b;
+            }
         }
+        // the softplus partials of the row's column tiles join the same reduction, one per lane (a single lane walking 2 x 16
+        // partials in dependent loads was the longest chain of this launch)
+        for (int i = lane; i < a.ncol_tiles; i += 64) t += a.rowpart[(size_t)i * a.ld_rowpart + row];
+        for (int i = lane; i < a.ncol_tiles1; i += 64) t1 += a.rowpart1[(size_t)i * a.ld_rowpart + row];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            t += x[e].x * b[e].x + x[e].y * b[e].y + x[e].z * b[e].z + x[e].w * b[e].w;
-            t1 += y[e].x * b[e].x + y[e].y * b[e].y + y[e].z * b[e].z + y[e].w * b[e].w;
+        for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); t1 += __shfl_xor(t1, o); }
+        if (lane == 0) {
+            const float F = -t, F1 = -t1;
+            if (a.F) { a.F[row] = F; a.F[a.rows + row] = F1; }
+            a.absdiff[row] = fabsf(F - F1);
         }
-    }
-    for (int c = 4 * n4 + lane; c < a.n_vis; c += 64) {      // (n_vis % 4 columns)
-        const float b = a.b_v[c];
-        t += vr[c] * b;
-        t1 += v1r[c] * b;
-    }
-    // the softplus partials of the row's column tiles join the same reduction, one per lane (a single lane walking 2 x 16
-    // partials in dependent loads was the longest chain of this launch)
-    for (int i = lane; i < a.ncol_tiles; i += 64) t += a.rowpart[(size_t)i * a.ld_rowpart + row];
-    for (int i = lane; i < a.ncol_tiles1; i += 64) t1 += a.rowpart1[(size_t)i * a.ld_rowpart + row];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); t1 += __shfl_xor(t1, o); }
-    if (lane == 0) {
-        const float F = -t, F1 = -t1;
-        if (a.F) { a.F[row] = F; a.F[a.rows + row] = F1; }
-        a.absdiff[row] = fabsf(F - F1);
     }
 }
 
+// (one block: the rows' |F - F'| added in a fixed order, in double.  Folded into k_score_rows as "the last workgroup to finish" it
+//  was SLOWER -- 1 024 workgroups draining write-through stores and one of them reading 4 096 values past the L2: round 4)
 __global__ __launch_bounds__(1024) void k_score_mean(ScoreArgs a) {
     __shared__ double part[1024];
     double s = 0.;

@@ -30,30 +30,38 @@ namespace kurbm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// all workgroups of the grid have arrived (and their writes are visible device-wide); false after a timeout
+// All workgroups of the grid have arrived; false after a timeout.  NO fences: an agent-scope release writes back a whole L2 and an
+// acquire invalidates it (tens of microseconds per barrier here: the first version of this kernel took 180 us per step for it).
+// Instead the planes that cross a barrier -- h_pos, v_neg, h_neg -- are written by agent-scope (write-through) stores and read by
+// agent-scope loads (past this CU's L1 and this XCD's L2); a wave drains its stores before it arrives; W, the biases and the batch
+// are read-only until the last phase.
 __device__ bool grid_barrier(const SmallArgs& a, unsigned& gen) {
     __shared__ int ok;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // this workgroup's plane stores: written back past its XCD's L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         ok = 1;
-        const unsigned arrived = __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned arrived = __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == gridDim.x - 1) {
             __hip_atomic_store(a.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.bar + 1, gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the counter is back at zero before anybody can arrive again)
+            __hip_atomic_store(a.bar + 1, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             const unsigned long long t0 = realtime_ticks();
-            while (__hip_atomic_load(a.bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                __builtin_amdgcn_s_sleep(2);
+            while (__hip_atomic_load(a.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(1);
                 if (realtime_ticks() - t0 > a.timeout_ticks) { ok = 0; break; }
             }
         }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // the other workgroups' stores, not this CU's stale lines
     ++gen;
     return ok != 0;
 }
+
+// plane accessors: agent scope (see grid_barrier)
+__device__ __forceinline__ float ld_plane(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_plane(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // One 16 x 16 tile of C = A . B over the k chunks [c0, c1) of 16 (stride cs): the lane (x = lane & 15, slot = lane >> 4) feeds
 // k = 16 c + 4 slot + e to MFMA e of a chunk -- A and B agree on that map, so any operand layout works:
@@ -61,35 +69,50 @@ __device__ bool grid_barrier(const SmallArgs& a, unsigned& gen) {
 //   KS (k strided):               four 4-byte loads per chunk     X[k][x]  = base[k * ld + x]
 // x_ok / k < K guard ragged shapes (zeros contribute nothing).  NEG: the A values enter negated.
 // A and B point at the TILE (KC: its first row; KS: its first column), so x = lane & 15 indexes both.
-template <bool A_KC, bool B_KC, bool NEG>
+// A_PL / B_PL: the operand is a plane another workgroup wrote in an earlier phase -- agent-scope dword loads.
+template <bool A_KC, bool B_KC, bool NEG, bool A_PL = false, bool B_PL = false>
 __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A, int lda, bool a_ok, const float* __restrict__ B, int ldb, bool b_ok,
                                          int K, int c0, int c1, int cs, int x, int slot) {
-    for (int c = c0; c < c1; c += cs) {
-        const int k = 16 * c + 4 * slot;
-        float av[4], bv[4];
-        if (A_KC) {
-            if (a_ok && k + 3 < K) { const f32x4 t = *reinterpret_cast<const f32x4*>(A + (size_t)x * lda + k); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
-            else for (int e = 0; e < 4; ++e) av[e] = (a_ok && k + e < K) ? A[(size_t)x * lda + k + e] : 0.f;
-        } else {
+    // UN chunks at a time: ALL their loads are issued before the first MFMA -- the operands come from L2 with a few waves per CU, so
+    // a chunk-by-chunk loop would pay one L2 round trip per chunk (it did: 40 us per phase)
+    constexpr int UN = 8;
+    for (int cb = c0; cb < c1; cb += UN * cs) {
+        float av[UN][4], bv[UN][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[e] = (a_ok && k + e < K) ? A[(size_t)(k + e) * lda + x] : 0.f;
+        for (int u = 0; u < UN; ++u) {
+            const int c = cb + u * cs;
+            const int k = 16 * c + 4 * slot;
+            const bool live = c < c1;
+            if (A_KC) {
+                if (!A_PL && live && a_ok && k + 3 < K) { const f32x4 t = *reinterpret_cast<const f32x4*>(A + (size_t)x * lda + k); av[u][0] = t.x; av[u][1] = t.y; av[u][2] = t.z; av[u][3] = t.w; }
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[u][e] = (live && a_ok && k + e < K) ? (A_PL ? ld_plane(A + (size_t)x * lda + k + e) : A[(size_t)x * lda + k + e]) : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[u][e] = (live && a_ok && k + e < K) ? (A_PL ? ld_plane(A + (size_t)(k + e) * lda + x) : A[(size_t)(k + e) * lda + x]) : 0.f;
+            }
+            if (B_KC) {
+                if (live && b_ok && k + 3 < K) { const f32x4 t = *reinterpret_cast<const f32x4*>(B + (size_t)x * ldb + k); bv[u][0] = t.x; bv[u][1] = t.y; bv[u][2] = t.z; bv[u][3] = t.w; }
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[u][e] = (live && b_ok && k + e < K) ? B[(size_t)x * ldb + k + e] : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[u][e] = (live && b_ok && k + e < K) ? (B_PL ? ld_plane(B + (size_t)(k + e) * ldb + x) : B[(size_t)(k + e) * ldb + x]) : 0.f;
+            }
         }
-        if (B_KC) {
-            if (b_ok && k + 3 < K) { const f32x4 t = *reinterpret_cast<const f32x4*>(B + (size_t)x * ldb + k); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
-            else for (int e = 0; e < 4; ++e) bv[e] = (b_ok && k + e < K) ? B[(size_t)x * ldb + k + e] : 0.f;
-        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = (b_ok && k + e < K) ? B[(size_t)(k + e) * ldb + x] : 0.f;
-        }
+        for (int u = 0; u < UN; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(NEG ? -av[e] : av[e], bv[e], acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(NEG ? -av[u][e] : av[u][e], bv[u][e], acc, 0, 0, 0);
     }
 }
 
 // A half step over all 16 x 16 tiles of out [rows][N]: a workgroup takes tiles blockIdx.x, + gridDim.x, ...; its four waves
 // split the k chunks and meet in LDS (added in wave order); wave 0 finishes the tile: bias, activation, draw, store.
 // HV = false: out = f(in . W + b_h) (k = visible units, W read as [k][n]); HV = true: out = f(in . W^T + b_v) (W read as [n][k]).
-template <bool HV>
+template <bool HV, bool IN_PL>
 __device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in, int ld_in, float* __restrict__ out, int ldo, int act,
                                 int noise, const RngArgs& rng, float* red) {
     const int K = HV ? a.n_hid : a.n_vis, N = HV ? a.n_vis : a.n_hid;
@@ -101,8 +124,8 @@ __device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in
         const int m = tm * 16 + x, n = tn * 16 + x;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* At = in + (size_t)tm * 16 * ld_in;                                      // rows of the batch, k contiguous
-        if (HV) tile_mma<true, true, false>(acc, At, ld_in, m < a.rows, a.W + (size_t)tn * 16 * a.ldw, a.ldw, n < N, K, wave, nch, 4, x, slot);   // W^T: rows = visible units
-        else    tile_mma<true, false, false>(acc, At, ld_in, m < a.rows, a.W + tn * 16, a.ldw, n < N, K, wave, nch, 4, x, slot);                 // W as [k][n]
+        if (HV) tile_mma<true, true, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + (size_t)tn * 16 * a.ldw, a.ldw, n < N, K, wave, nch, 4, x, slot);   // W^T: rows = visible units
+        else    tile_mma<true, false, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + tn * 16, a.ldw, n < N, K, wave, nch, 4, x, slot);                 // W as [k][n]
         *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc;
         __syncthreads();
         if (wave == 0) {
@@ -124,7 +147,7 @@ __device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in
                     float y = p;
                     if (noise == NOISE_BERNOULLI) y = (u32_to_unit(w1[r]) < p) ? 1.f : 0.f;
                     else if (noise == NOISE_GAUSSIAN) y = p + box_muller(u32_to_unit(w1[r]), u32_to_unit(w2[r]));
-                    if (row0 + r < a.rows) out[(size_t)(row0 + r) * ldo + col] = y;
+                    if (row0 + r < a.rows) st_plane(out + (size_t)(row0 + r) * ldo + col, y);
                 }
             }
         }
@@ -139,15 +162,27 @@ __global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
     gen = __builtin_amdgcn_readfirstlane(gen);   // (only thread 0 uses it; uniform for tidiness)
     const int act_h = a.gauss ? ACT_RELU : ACT_SIGMOID, act_v = a.gauss ? ACT_LINEAR : ACT_SIGMOID;
     bool ok = true;
+#ifdef KURBM_SMALL_STAMPS   // diagnostic build: phase boundaries of workgroup 0 (100 MHz ticks) into words 40.. of the status block
+#define KURBM_SST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.status + 40)[i] = realtime_ticks(); } while (0)
+#else
+#define KURBM_SST(i) do { } while (0)
+#endif
+    KURBM_SST(0);
     // 1: h_pos ~ p(h | v_pos)                                                   rbm.py:120
-    half_step_small<false>(a, a.v, a.ldv, a.h_pos, a.ldh, act_h, NOISE_BERNOULLI, a.rng_h, red);
+    half_step_small<false, false>(a, a.v, a.ldv, a.h_pos, a.ldh, act_h, NOISE_BERNOULLI, a.rng_h, red);
+    KURBM_SST(1);
     ok = grid_barrier(a, gen) && ok;
+    KURBM_SST(2);
     // 2: v_neg ~ p(v | h_pos)                                                   rbm.py:121-123 / :143-144
-    if (ok) half_step_small<true>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red);
+    if (ok) half_step_small<true, true>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red);
+    KURBM_SST(3);
     ok = grid_barrier(a, gen) && ok;
+    KURBM_SST(4);
     // 3: h_neg = sigmoid(v_neg . W + b_h): probabilities in both modes          rbm.py:124 / :145
-    if (ok) half_step_small<false>(a, a.v_neg, a.ldn, a.h_neg, a.ldh, ACT_SIGMOID, NOISE_NONE, a.rng_h, red);
+    if (ok) half_step_small<false, true>(a, a.v_neg, a.ldn, a.h_neg, a.ldh, ACT_SIGMOID, NOISE_NONE, a.rng_h, red);
+    KURBM_SST(5);
     ok = grid_barrier(a, gen) && ok;
+    KURBM_SST(6);
     if (!ok) {
         if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -163,8 +198,8 @@ __global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
             const int i = ti * 16 + x, j = tj * 16 + x;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             // dW = v_pos^T . h_pos - v_neg^T . h_neg   (rbm.py:125-126), k = the batch rows: both operands k-strided
-            tile_mma<false, false, false>(acc, a.v + ti * 16, a.ldv, i < a.n_vis, a.h_pos + tj * 16, a.ldh, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
-            tile_mma<false, false, true>(acc, a.v_neg + ti * 16, a.ldn, i < a.n_vis, a.h_neg + tj * 16, a.ldh, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+            tile_mma<false, false, false, false, true>(acc, a.v + ti * 16, a.ldv, i < a.n_vis, a.h_pos + tj * 16, a.ldh, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+            tile_mma<false, false, true, true, true>(acc, a.v_neg + ti * 16, a.ldn, i < a.n_vis, a.h_neg + tj * 16, a.ldh, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
             const int col = tj * 16 + x, row0 = ti * 16 + 4 * slot;
             if (col < a.n_hid)
 #pragma unroll
@@ -186,7 +221,7 @@ __global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int r = r0 + 4 * e;
-                        d[e] = r < a.rows ? pos[(size_t)r * ldp + col] - neg[(size_t)r * ldq + col] : 0.f;
+                        d[e] = r < a.rows ? (hid ? ld_plane(pos + (size_t)r * ldp + col) : pos[(size_t)r * ldp + col]) - ld_plane(neg + (size_t)r * ldq + col) : 0.f;
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) s += d[e];
@@ -199,6 +234,7 @@ __global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
             }
         }
     }
+    KURBM_SST(7);
 }
 
 hipError_t launch_cd1_small(const SmallArgs& a, int nblk, hipStream_t st) {

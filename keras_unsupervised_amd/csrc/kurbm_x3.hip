@@ -1566,11 +1566,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float t = rsum[mi][r];
-                t += __shfl_xor(t, 1);
-                t += __shfl_xor(t, 2);
-                t += __shfl_xor(t, 4);
-                t += __shfl_xor(t, 8);
+                const float t = row16_sum(rsum[mi][r]);
                 if (l15 == 0) red[wn * BM + wm * WM + mi * 16 + slot * 4 + r] = t;
             }
         __syncthreads();
@@ -1606,11 +1602,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float t = rsum[mi][r];
-                t += __shfl_xor(t, 1);
-                t += __shfl_xor(t, 2);
-                t += __shfl_xor(t, 4);
-                t += __shfl_xor(t, 8);
+                const float t = row16_sum(rsum[mi][r]);
                 if (l15 == 0) red[wn * BM + wm * WM + mi * 16 + slot * 4 + r] = t;
             }
         __syncthreads();

@@ -49,7 +49,10 @@ def report(name, s):
 
 planes = eng.make_planes(V, [(0, B)], mode)
 step = lambda: eng.cd_step(V, B, 0, 1e-3 / B, 42, 0, mode=mode, compute="x3", planes=planes)
-print("data %s, mode %s" % (kind, "gauss" if mode else "bern"))
+what = sys.argv[3] if len(sys.argv) > 3 else "step"
+if what == "score":   # the score pass of fit(verbose=1): three GEMM launches (kurbm_score_x3)
+    step = lambda: eng.score_x3(V, B, 0, 42, 0, mode, 3, planes=planes)
+print("data %s, mode %s, %s" % (kind, "gauss" if mode else "bern", what))
 for _ in range(3):
     step()
 torch.cuda.synchronize()
@@ -59,7 +62,7 @@ step()
 torch.cuda.synchronize()
 lib.kurbm_debug_set_stamp_buffer(None)
 s = buf.cpu().numpy().astype(np.float64).reshape(4, 512, 8, 16)
-for n, name in enumerate(("vh sample", "hv sample", "vh prob", "statistics")):
+for n, name in enumerate(("vh sample", "hv sample", "vh prob", "statistics") if what == "step" else ("vh + F(v)", "hv -> v'", "F(v')")):
     report(name, s[n, :, 0])
     lw = s[n, :, 7]
     lw = lw[lw[:, 0] == 1]
