@@ -52,6 +52,7 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
                                    //    negative half on byte planes (Bernoulli visibles) or on the paired walk (Gaussian visibles)
 };
 
+constexpr size_t STATUS_BYTES = 4096;
 struct kurbm_ctx {
     int device;
     int ncu;
@@ -60,7 +61,9 @@ struct kurbm_ctx {
     int force_split;    // KURBM_SPLIT
     int tile_major;     // KURBM_TILE_MAJOR (default 1): k-slices of a statistics tile share an XCD
     int knob[KN_COUNT];
-    unsigned* status;   // device word, sticky: kurbm_ctx_status (the only device memory the library owns: 256 bytes)
+    unsigned* status;   // device word, sticky: kurbm_ctx_status, in front of the only device memory the library owns (STATUS_BYTES: behind
+                        // the status word the grid barrier of kurbm_cd_step_small -- words 64 .. 223: eight per-XCD arrival counters, the
+                        // grid's counter, the generation word, one 64-byte line each)
 };
 
 static int env_int(const char* name, int dflt) {
@@ -303,8 +306,8 @@ int kurbm_ctx_create(int device, kurbm_ctx** out) {
         int prev = 0;
         (void)hipGetDevice(&prev);
         hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->status), 256);
-        if (e == hipSuccess) e = hipMemset(c->status, 0, 256);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->status), STATUS_BYTES);
+        if (e == hipSuccess) e = hipMemset(c->status, 0, STATUS_BYTES);
         (void)hipSetDevice(prev);
         if (e != hipSuccess) {
             if (c->status) (void)hipFree(c->status);
@@ -320,7 +323,7 @@ int kurbm_ctx_status(kurbm_ctx* ctx, int* bits) {
     if (!ctx || !bits) return fail(KURBM_ERR_ARG, "null argument");
     unsigned v = 0;
     HIP_TRY(hipMemcpy(&v, ctx->status, sizeof v, hipMemcpyDeviceToHost));      // (synchronises with the device)
-    if (v) HIP_TRY(hipMemset(ctx->status, 0, 256));      // (also re-arms the grid barrier of kurbm_cd_step_small: words 16, 17)
+    if (v) HIP_TRY(hipMemset(ctx->status, 0, STATUS_BYTES));      // (also re-arms the grid barrier of kurbm_cd_step_small)
     *bits = (int)v;
     return KURBM_OK;
 }
@@ -503,7 +506,7 @@ int kurbm_cd_step_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_ba
     a.W = p->W; a.b_h = p->b_h; a.b_v = p->b_v; a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw;
     a.v = v_batch; a.rows = rows; a.ldv = ldv;
     a.h_pos = w.h_pos; a.h_neg = w.h_neg; a.v_neg = w.v_neg; a.ldh = w.ldh; a.ldn = w.ldv;
-    a.bar = ctx->status + 16; a.status = ctx->status;
+    a.bar = ctx->status + 64; a.status = ctx->status;
     a.timeout_ticks = 200000000ull;          // 2 s of the 100 MHz clock: only a grid that is not resident ever gets there
     const uint32_t base = o->chain * 64u;
     a.rng_h = make_rng(o->seed, o->row0, base + 0u, o->step);
@@ -1412,7 +1415,6 @@ int kurbm_score_x3(kurbm_ctx* ctx, const kurbm_params* p, void* mirror, size_t m
     ScoreArgs a;
     memset(&a, 0, sizeof a);
     if (nbytes) { a.v1b = reinterpret_cast<const unsigned char*>(w.v2b); a.ldv1b = w.Lv; }
-    a.counter = ctx->status + 32;
     a.v = v_batch; a.v1 = w.tmp32; a.b_v = p->b_v; a.rowpart = rp0; a.rowpart1 = rp1; a.F = F; a.absdiff = absdiff; a.score = score;
     a.rows = rows; a.n_vis = p->n_vis; a.ldv = ldv; a.ldv1 = w.ldv32; a.ncol_tiles = ncol0; a.ncol_tiles1 = ncol1; a.ld_rowpart = ld_rp;
     HIP_TRY(launch_score(a, st));                                                                      // mean |F - F'|  rbm.py:233

@@ -176,7 +176,6 @@ struct ScoreArgs {
     const float* v1;       // [rows][ldv1] its one-step reconstruction v' (fp32 plane), or:
     const unsigned char* v1b;   // v' as a byte plane of 0/1 values (0x40 = one, k-permuted: kperm64), ldv1b bytes per row; then v1 is unused
     int ldv1b;
-    unsigned* counter;     // arrival counter of the launch (zero between launches: the last workgroup resets it)
     const float* b_v;
     const float* rowpart;  // [ncol_tiles][ld_rowpart] of v
     const float* rowpart1; // ... of v'
@@ -354,7 +353,7 @@ struct SmallArgs {
     float* W; float* b_h; float* b_v;
     const float* v;
     float* h_pos; float* v_neg; float* h_neg;     // workspace planes [rows][ldh] / [rows][ldn]
-    unsigned* bar;                                 // {arrival count, generation}: two words of the context's status block
+    unsigned* bar;                                 // the grid barrier's words in the context's status block (kurbm_small.hip: grid_barrier)
     unsigned* status;
     unsigned long long timeout_ticks;              // of the 100 MHz constant clock
     RngArgs rng_h, rng_v;                          // the counters of the h_pos and v_neg sampling sites

@@ -30,25 +30,38 @@ namespace kurbm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// All workgroups of the grid have arrived; false after a timeout.  NO fences: an agent-scope release writes back a whole L2 and an
-// acquire invalidates it (tens of microseconds per barrier here: the first version of this kernel took 180 us per step for it).
-// Instead the planes that cross a barrier -- h_pos, v_neg, h_neg -- are written by agent-scope (write-through) stores and read by
-// agent-scope loads (past this CU's L1 and this XCD's L2); a wave drains its stores before it arrives; W, the biases and the batch
-// are read-only until the last phase.
+// All workgroups of the grid have arrived; false after a timeout.
+// * No RELEASE fence: an agent-scope release writes back a whole L2 (the first version of this kernel took 180 us per step for its
+//   fences).  The planes that cross a barrier -- h_pos, v_neg, h_neg -- are written by agent-scope (write-through) stores and a wave
+//   drains its stores before it arrives; they are read by agent-scope loads (past this CU's L1 and this XCD's L2), so no acquire
+//   either (one invalidate behind the barrier and plain loads instead: 73 against 53 us per step -- every phase loses its cached W).
+// * Two levels: a workgroup arrives on the counter of its XCD (workgroup i runs on XCD i % 8), the last one of an XCD on the grid's
+//   counter, the last of those bumps the generation word everybody polls -- 256 arrivals on ONE address are 256 serialised atomics
+//   at the memory side (~4 us); 32 on each of eight addresses in parallel, then 8, are not.
 __device__ bool grid_barrier(const SmallArgs& a, unsigned& gen) {
     __shared__ int ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         ok = 1;
-        const unsigned arrived = __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == gridDim.x - 1) {
-            __hip_atomic_store(a.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the counter is back at zero before anybody can arrive again)
-            __hip_atomic_store(a.bar + 1, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int xcd = blockIdx.x & 7, nx = ((int)gridDim.x - xcd + 7) >> 3, ngroups = gridDim.x < 8 ? (int)gridDim.x : 8;
+        unsigned* cx = a.bar + 16 * xcd;          // one 64-byte line per counter
+        unsigned* cg = a.bar + 16 * 8;
+        unsigned* gw = a.bar + 16 * 9;
+        bool bump = false;
+        if (__hip_atomic_fetch_add(cx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nx - 1u) {
+            __hip_atomic_store(cx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(cg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ngroups - 1u) {
+                __hip_atomic_store(cg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bump = true;
+            }
+        }
+        if (bump) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the counters are back at zero before anybody can arrive again)
+            __hip_atomic_store(gw, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             const unsigned long long t0 = realtime_ticks();
-            while (__hip_atomic_load(a.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+            while (__hip_atomic_load(gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
                 __builtin_amdgcn_s_sleep(1);
                 if (realtime_ticks() - t0 > a.timeout_ticks) { ok = 0; break; }
             }
@@ -74,7 +87,9 @@ template <bool A_KC, bool B_KC, bool NEG, bool A_PL = false, bool B_PL = false>
 __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A, int lda, bool a_ok, const float* __restrict__ B, int ldb, bool b_ok,
                                          int K, int c0, int c1, int cs, int x, int slot) {
     // UN chunks at a time: ALL their loads are issued before the first MFMA -- the operands come from L2 with a few waves per CU, so
-    // a chunk-by-chunk loop would pay one L2 round trip per chunk (it did: 40 us per phase)
+    // a chunk-by-chunk loop would pay one L2 round trip per chunk.  (Built and measured, round 4, and NOT kept: 16 chunks per batch
+    // with every load unconditional on clamped indices and a select behind it, one tile per wave for h -> v -- every phase took
+    // 10-14 us whatever the batch, 60 against 47 us per step.)
     constexpr int UN = 8;
     for (int cb = c0; cb < c1; cb += UN * cs) {
         float av[UN][4], bv[UN][4];
@@ -158,7 +173,7 @@ __device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in
 __global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
     unsigned gen = 0;
-    if (threadIdx.x == 0) gen = __hip_atomic_load(a.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) gen = __hip_atomic_load(a.bar + 16 * 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     gen = __builtin_amdgcn_readfirstlane(gen);   // (only thread 0 uses it; uniform for tidiness)
     const int act_h = a.gauss ? ACT_RELU : ACT_SIGMOID, act_v = a.gauss ? ACT_LINEAR : ACT_SIGMOID;
     bool ok = true;

@@ -373,8 +373,11 @@ class RBM(object):
         c = self.compute_dtype
         if c == "auto":
             c = "x3" if int(self.hps["batch_size"]) >= 256 else "small"
-        if c == "small" and (self.cd_k != 1 or self.persistent or dp.world()[1] > 1):
-            c = "fp32"        # the one-launch step is CD-1 from the data on one GPU; everything else takes the five-launch path
+        if c == "small" and (self.cd_k != 1 or self.persistent or dp.world()[1] > 1 or
+                             (self.compute_dtype == "auto" and (int(self.hps["batch_size"]) > 128 or self.output_dim > 256))):
+            # the one-launch step is CD-1 from the data on one GPU; 'auto' takes it where it wins (tools/small_times.py: up to
+            # batch 128 and 256 hidden units); everything else runs the five-launch path
+            c = "fp32"
         return c
 
     def _update_local(self, Vd, lo, rows, lr, step):
