@@ -13,21 +13,35 @@
 // 0 .. npb-1 of B of the same set; set 1 is the negative phase of the statistics (its B planes are stored negated).  A
 // real-valued A (grey-level data) is three segments (ia = 0, 1, 2 with npb = 3, 2, 1).
 //
-// Tile 128 x 128 (statistics) or 256 x 64 (half steps), k-tile 64 (swizzled 128-byte LDS rows), 8 MFMA waves of 64 x 32
-// outputs, two per SIMD (while one waits for LDS or the barrier the other issues MFMAs), beside 4 loader waves that stage by
-// LDS-DMA (below).  B fragments are read two micro-steps ahead.  Two LDS stages, one barrier per tile; one-piece tiles (the
-// rounded-bf16 path) three stages, tiles requested two ahead.
+// One kernel, k_gemm_pb<BM, BN, WAVES_M, WAVES_N, 64, PB, EPI, NOISE, AB, RP>: 768 threads = 8 MFMA waves of 64 x 32 outputs (two per
+// SIMD: while one waits for LDS or the barrier the other issues MFMAs) + 4 LOADER waves that stage by LDS-DMA; k-tile 64 in bare
+// 128-byte LDS rows, chunk-swizzled; one barrier per tile; B fragments read two micro-steps ahead.  What runs where (round 4):
+//   half steps on 0/1 states (AB)      256 x 64, the A operand a k-permuted BYTE plane (128-deep A blocks, v_perm_b32 expansion),
+//                                      two B stages, no tile list: one tile body, running offsets
+//   statistics, 0/1 data (ABS)         256 x 64, split-K 4, units of [fp8 tile | 3-piece | 3-piece] on byte planes, three A buffers,
+//                                      every request 10 pieces per wave at least a tile ahead of its reader
+//   half steps on a 3-piece batch,     128 x 128, the PAIRED walk (BSP): two tiles of 48 MFMAs per wave and k position, four A stages
+//   negative statistics of Gaussian      beside two B stages (160 KB)
+//   visibles
+//   statistics of real-valued data     two launches: the positive half TRANSPOSED (A = h_pos^T as bytes, B = the pieces of v_pos^T;
+//   (ABP: template slot RP on EPI_SLAB)  the tile leaves transposed into ordinary slabs), the negative half on bytes or on BSP
+//   one-piece tiles (rounded bf16)     128 x 128, four B stages + three A blocks, tiles requested four ahead, fragments read a tile
+//                                      ahead across the barrier (DEEP)
+//   older walks kept behind knobs      BSH / BSH2 (three tiles per k position sharing one B staging: KURBM_X3_PAIR=0 /
+//                                      KURBM_X3_SPLIT_STATS=0), the generic two-stage walk of a tile list (ragged shapes)
+// Entry: the argument segment warmed in one batch (kurbm_device.h), block mapping by multiply-high constants into XCD-aware 2-D
+// blocks, the loaders at high priority until their first requests are out.
 //
-// Epilogue of a half step, from registers: bias + activation + Philox draw; column sums of the value plane (bias
-// statistics); the transposed plane(s) as 8-byte (bf16) or 4-byte (fp8) stores (a lane holds 4 consecutive rows of its
-// column); only the row-major plane (bytes of a 0/1 sample, else bf16) takes a trip through LDS (patch of the whole tile,
-// then 16-byte coalesced rows).
+// Epilogue of a half step, from registers: bias + activation + Philox draw (the words of a lane's first columns drawn in the prologue
+// and parked in LDS); column sums of the value plane (bias statistics); the transposed plane(s) in 16-byte stores after a 4 x 4
+// transpose across lanes (v_permlane32_swap / v_permlane16_swap): fp8 or k-permuted bytes for a 0/1 sample, three negated bf16 pieces
+// for h_neg; only the row-major plane (bytes of a 0/1 sample, else bf16 pieces) takes a trip through LDS.  RP: also the softplus row
+// sums of F(v) from the same accumulators (the score), by DPP adds.
 //
-// Measured (MI355X, config 2, end of round 2; DESIGN.md section 4, profiles/r02_e_*, r02_f_*): sampling half steps 25.2 us, vh
-// prob 24.8 (about 4 us until the first tile has landed, 14 tiles of about 2 100 cycles for 1 536 of MFMA issue, 2-3 us draw
-// + sigmoid, 3-4 us of plane write-back), the statistics GEMM 28.7 us; MFMA busy 39-46 %, L2 hit rate 76-80 %, LDS bank
-// conflicts <= 1.5 %.  What bounds the loop (the loaders' DMA round trip on bf16 planes, the MFMA waves on byte planes) and
-// everything that was tried and dropped: DESIGN.md section 4.
+// Measured (MI355X, config 2, round 4, sustained loops; DESIGN.md section 4, profiles/r04_*): sampling half steps 20.1 / 22.4 us, v -> h
+// prob 21.7, statistics 22.1-22.8 (0.40-0.42 of its MFMA time at the dense peaks), slab reduce + mirrors 9.3; per launch ~2.4 us to
+// the first fragments, ~1 920 cycles per 1 536-cycle tile, 2-3 us of draws + sigmoid, 3-4 us of plane write-back.  Everything that
+// was tried and dropped: LABBOOK.md.
 //
 // Reference op sequences: ku/ebm/rbm.py:46-47 (v->h), :52-53 / :121-123 (h->v), :124 (h_neg), :125-134
 // (statistics); the split is an implementation choice of this build.
