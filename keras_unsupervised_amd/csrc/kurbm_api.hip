@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_BSHARE, KN_X3_PAIR, KN_X3_SPLIT_STATS,
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_BSHARE, KN_X3_PAIR, KN_X3_SPLIT_STATS, KN_X3_ATR,
        KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
@@ -50,6 +50,8 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_X3_SPLIT_STATS", 1},   // 0: the statistics of real-valued data in ONE launch (round 3: three one-piece positive tiles per k position);
                                    //    1: two launches -- the positive half as the transposed problem h_pos^T (bytes) x the pieces of v_pos^T, the
                                    //    negative half on byte planes (Bernoulli visibles) or on the paired walk (Gaussian visibles)
+    {"KURBM_X3_ATR", 1},           // 0: Gaussian visibles leave the h -> v half step as pieces in BOTH orientations; 1: row-major only, and the
+                                   //    negative statistics read them through transposed LDS reads (with KURBM_X3_SPLIT_STATS)
 };
 
 constexpr size_t STATUS_BYTES = 4096;
@@ -840,6 +842,7 @@ static inline uint32_t inv_of(int nkt) { return nkt > 1 ? (uint32_t)(0x100000000
 struct HalfOutB {
     uint16_t* out = nullptr; int ldo = 0;                 // bf16 value plane, row-major
     int out_pieces = 1; size_t out_plane = 0;             // (x3, real-valued plane: its three pieces)
+    int out_rows_pad = 0;                                 // rows [rows, out_rows_pad) of that plane are written as zeros
     uint16_t* outT = nullptr; int ldoT = 0;               // ... transposed
     int outT_pieces = 1; size_t outT_plane = 0;
     bool outT_neg = false;                                // the transposed plane is stored negated
@@ -897,7 +900,7 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.act = act; g.noise = noise;
         if (rng) g.rng = *rng;
         g.out = o.out; g.ldo = o.ldo; g.ldo_cols = o.out ? o.ldo : g.N;
-        g.out_pieces = o.out_pieces; g.out_plane = o.out_plane; g.out_bytes = o.out_bytes ? 1 : 0;
+        g.out_pieces = o.out_pieces; g.out_plane = o.out_plane; g.out_bytes = o.out_bytes ? 1 : 0; g.out_rows_pad = o.out_rows_pad;
         g.outT = o.outT; g.ldoT = o.ldoT; g.outT_pieces = o.outT_pieces; g.outT_plane = o.outT_plane;
         g.outT_neg = o.outT_neg ? 1 : 0; g.outT_f8 = o.outT_b8 ? 2 : o.outT_f8 ? 1 : 0;
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
@@ -997,6 +1000,12 @@ static bool split_stats_on(const kurbm_ctx* ctx, int pieces, int v_pieces) {
     return pieces == 3 && v_pieces == 3 && ctx->knob[KN_X3_SPLIT_STATS] != 0 && ctx->knob[KN_X3_BYTES] != 0;
 }
 
+// ... and the negative statistics of Gaussian visibles read v_neg's ROW-MAJOR pieces (no transposed copy is written): needs the
+// paired walk on 128 x 128 tiles, whose LDS rows are then the plane's 128-column blocks (n_vis padded to 128 = the plane's ld)
+static bool atr_on(const kurbm_ctx* ctx, int pieces, int v_pieces, bool gauss) {
+    return gauss && split_stats_on(ctx, pieces, v_pieces) && ctx->knob[KN_X3_ATR] != 0 && ctx->knob[KN_X3_PAIR] != 0 && ctx->knob[KN_LDPAD] == 0;
+}
+
 static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_params* p, void* mirror, size_t mirror_bytes,
                        const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o, int which, void* workspace,
                        size_t workspace_bytes, kurbm_stream_t stream, int only = -1, int m_lo = 0, int m_hi = -1) {
@@ -1034,6 +1043,9 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
     // real-valued data: the statistics as two launches (plan_split_stats), h_pos^T -- and v_neg^T of Bernoulli visibles -- as byte planes
     const bool split_stats = split_stats_on(ctx, pieces, v_pieces);
     const bool tbytes_n = tbytes || (split_stats && nbytes);
+    // ... and Gaussian visibles need no transposed copy of v_neg at all: the paired walk of the negative statistics reads the row-major
+    // pieces through transposed LDS reads (k_gemm_pb, "ATR")
+    const bool vneg_tr = atr_on(ctx, pieces, v_pieces, gauss);
     int e;
 
     // v_pos -> bf16 pieces, row-major (A of the v->h step) and transposed (statistics)
@@ -1075,7 +1087,8 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             HalfOutB ho;
             ho.out = w.v2b; ho.ldo = w.Lv; ho.out_pieces = vn_pieces; ho.out_plane = w.planeV; ho.out_bytes = nbytes;
             if (last) {
-                ho.outT = w.v2bT; ho.ldoT = w.Lb; ho.outT_pieces = vn_pieces; ho.outT_plane = w.planeVT; ho.outT_b8 = tbytes_n;
+                if (vneg_tr) ho.out_rows_pad = w.Kb;      // (the statistics walk the batch padded to 128 rows of this plane)
+                if (!vneg_tr) { ho.outT = w.v2bT; ho.ldoT = w.Lb; ho.outT_pieces = vn_pieces; ho.outT_plane = w.planeVT; ho.outT_b8 = tbytes_n; }
                 ho.out_f32 = o->v_chain; ho.ldo32 = ldv;
                 ho.grid_m_out = &gm_v;
             }
@@ -1171,6 +1184,9 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             if (gauss) {   // (v_neg piece a) x (-h_neg pieces 0 .. 2 - a), two tiles per k position (k_gemm_pb, "BSP")
                 g.nseg = pb_codes(ctx, 3, 3, 0u, &g.seg_codes, 0);
                 g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg); g.pair_ok = 1;
+                if (vneg_tr) {   // A = the ROW-MAJOR pieces [batch][n_vis]: columns m_lo .. of them
+                    g.A0 = w.v2b + m_lo; g.a_plane0 = w.planeV; g.lda = w.Lv; g.a_tr = 1;
+                }
             } else {       // v_neg^T as bytes against the three pieces of -h_neg^T (k_gemm_pb, "ABP")
                 g.nseg = pb_codes(ctx, 1, 3, 0u, &g.seg_codes, 0);
                 g.a_bytes = 1; g.lda = 2 * w.Lb;
@@ -1444,6 +1460,9 @@ int kurbm_x3_dump_plane(kurbm_ctx* ctx, int which, int rows, int n_vis, int n_hi
                                   a.pieces = gauss ? 3 : 1; a.plane = w.planeV; break;
         case KURBM_PLANE_V_NEG_T: a.src = w.v2bT; a.units = n_vis; a.ld = w.Lb; a.transposed = 1;
                                   a.pieces = gauss ? 3 : 1; a.plane = w.planeVT;
+                                  if (atr_on(ctx, 3, v_pieces, gauss)) {   // (no transposed copy exists: the statistics read the row-major pieces)
+                                      a.src = w.v2b; a.ld = w.Lv; a.transposed = 0; a.plane = w.planeV;
+                                  }
                                   if ((f8pos && byt && !gauss && ctx->knob[KN_X3_STATS_BYTES] != 0 && ctx->knob[KN_X3_STATS_TALL] != 0 && n_vis > 128) ||
                                       (split_stats_on(ctx, 3, v_pieces) && !gauss)) {
                                       a.fmt = 1; a.ld = 2 * w.Lb;   // (bytes at the bf16 plane's row stride: cd_step_any, tbytes)

@@ -125,11 +125,10 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
 // buffers (kurbm_peer.hip) -- the rows of band q from rank q's `sum` region once its `summed` flag is up: the all-gather of the
 // two-shot all-reduce IS this launch's read.  Workgroup 0 also waits for EVERY rank's flag (a rank with an empty band still read
 // this rank's bias tail: nobody's `delta` may be rewritten before all are done).
-template <int TR, bool PEER = false>
-__global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int tiles_x, int tiles, int nbias, PeerSrc ps) {
-    warm_kernel_arguments<sizeof(ReduceArgs) + 16>();   // (kurbm_device.h: one wait for the argument segment, not one per use)
+template <int TR, bool PEER>
+__device__ __forceinline__ void reduce_apply_split_body(ReduceArgs& a, int tiles_x, int tiles, int nbias, const PeerSrc& ps) {
     __shared__ __attribute__((aligned(16))) float tile[TR][CVT + 1];
-    [[maybe_unused]] __shared__ int peer_ok;
+    __shared__ int peer_ok;
     const int t = threadIdx.x;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     if constexpr (PEER) {
@@ -232,6 +231,19 @@ __global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int ti
         return;
     }
 }
+// (two entry points: the ordinary launch does not carry the 184 bytes of peer pointers in its argument segment)
+template <int TR>
+__global__ __launch_bounds__(256) void k_reduce_apply_split(ReduceArgs a, int tiles_x, int tiles, int nbias) {
+    warm_kernel_arguments<sizeof(ReduceArgs) + 16>();   // (kurbm_device.h: one wait for the argument segment, not one per use)
+    PeerSrc none;
+    none.band_rows = 0;
+    reduce_apply_split_body<TR, false>(a, tiles_x, tiles, nbias, none);
+}
+template <int TR>
+__global__ __launch_bounds__(256) void k_reduce_apply_split_peer(ReduceArgs a, int tiles_x, int tiles, int nbias, PeerSrc ps) {
+    warm_kernel_arguments<sizeof(ReduceArgs) + 16 + sizeof(PeerSrc)>();
+    reduce_apply_split_body<TR, true>(a, tiles_x, tiles, nbias, ps);
+}
 
 // flag |= 1 if some element of `in` is not exactly representable in bf16, |= 2 if some element is neither 0.0 nor 1.0
 // (the caller zeroes it)
@@ -328,11 +340,11 @@ hipError_t launch_reduce_apply_split(const ReduceArgs& a, hipStream_t st, const 
     const int tiles_y = (r_ext + tr - 1) / tr;
     const dim3 grid(tiles_x * tiles_y + nb);
     if (ps.band_rows) {
-        if (tr == 32) hipLaunchKernelGGL((k_reduce_apply_split<32, true>), grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
-        else hipLaunchKernelGGL((k_reduce_apply_split<16, true>), grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
-    } else if (tr == 64) hipLaunchKernelGGL(k_reduce_apply_split<64>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
-    else if (tr == 32) hipLaunchKernelGGL(k_reduce_apply_split<32>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
-    else hipLaunchKernelGGL(k_reduce_apply_split<16>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
+        if (tr == 32) hipLaunchKernelGGL(k_reduce_apply_split_peer<32>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
+        else hipLaunchKernelGGL(k_reduce_apply_split_peer<16>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb, ps);
+    } else if (tr == 64) hipLaunchKernelGGL(k_reduce_apply_split<64>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb);
+    else if (tr == 32) hipLaunchKernelGGL(k_reduce_apply_split<32>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb);
+    else hipLaunchKernelGGL(k_reduce_apply_split<16>, grid, dim3(256), 0, st, a, tiles_x, tiles_x * tiles_y, nb);
     return hipGetLastError();
 }
 

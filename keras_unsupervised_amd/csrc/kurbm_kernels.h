@@ -271,6 +271,8 @@ struct GemmArgsB {
     int out_bytes;        // the row-major plane of a 0/1 sample leaves as BYTES (0x40 = one), ldo bytes between its rows
     size_t out_plane;
     int ldo_cols;         // columns the row planes cover: ldo when `out` is set (pads are zeroed), else N
+    int out_rows_pad;     // bf16 row-major plane: rows [M, out_rows_pad) are written as zeros (0: none) -- the statistics GEMM that reads the
+                          // plane as its A operand with k = the batch rows walks the batch padded to 128 (k_gemm_pb, "ATR")
     uint16_t* outT;       // bf16 [N][ldoT]  the same plane transposed; nullable
     int ldoT;
     int outT_pieces;      // 1: outT = round-to-nearest bf16; 3: exact hi / mid / lo pieces, outT_plane apart
@@ -293,6 +295,8 @@ struct GemmArgsB {
     int slab_t;           // EPI_SLAB on a byte-plane A operand (k_gemm_pb "ABP"): the tile leaves TRANSPOSED -- M counts the slab's COLUMNS,
                           // N its rows (the positive statistics of real-valued data as h_pos^T x the pieces of v_pos^T)
     int bshare_ok;        // caller: the statistics GEMM may share B stagings between the tiles of a k position (ctx knob KURBM_X3_BSHARE)
+    int a_tr;             // caller (paired walk of the statistics GEMM): A0 is a ROW-MAJOR plane [k][M], lda its leading dimension -- the
+                          // tiles are staged as [k][m] and read by transposed LDS reads (k_gemm_pb, "ATR")
     int pair_ok;          // caller: a real-valued A operand on 128 x 128 tiles may walk two tiles per k position (ctx knob KURBM_X3_PAIR; bshare = 2)
     int map_force;        // caller: 1 = map blocks by division whatever the grid (ctx knob KURBM_MAP_SLOW: tests of that path)
     int any_order;        // caller: TIMING ONLY -- launch without the AQL barrier bit (ctx knob KURBM_ANYORDER); results race

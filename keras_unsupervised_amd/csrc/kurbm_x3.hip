@@ -315,6 +315,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // involution as the fragment reads.  Rows outside the matrix are pointed at row 0 (they only feed outputs that
     // are never stored).  Loads are buffer loads: a per-lane BYTE offset that never changes (voffset) plus a per-tile
     // scalar offset (soffset) against one descriptor per operand -- no per-tile vector address arithmetic at all.
+    // ATR (g.a_tr; the paired walk of the statistics GEMM only): the A operand is read from a ROW-MAJOR plane [k][M] -- the pieces of
+    // v_neg as the h -> v half step leaves them for the next half step -- so that no transposed copy of them need be written (19 MB per
+    // Gaussian step).  The A tile then sits in LDS as 64 k rows of 256 bytes (128 m), chunk c of row r at c ^ (((r & 3) << 2) |
+    // ((r >> 2) & 3)) (cdna_hip_programming.md T10, image (b)), and the MFMA waves fetch their fragments with ds_read_b64_tr_b16: a lane
+    // needs 8 consecutive k of ONE m, i.e. a column of that image.
+    constexpr bool ATR = BSP && EPI == EPI_SLAB;
+    const bool a_tr = ATR && g.a_tr != 0;
     unsigned goffA[NA], goffB[NB1];
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
@@ -322,6 +329,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         const int x = (m0 + row < g.M) ? m0 + row : 0;
         // (a byte plane has lda BYTES between its rows; its 128-byte row piece is 128 k)
         goffA[it] = AB ? (unsigned)(x * g.lda + 16 * (ch ^ ((row >> 1) & 7))) : 2u * (unsigned)(x * g.lda + 8 * (ch ^ ((row >> 1) & 7)));
+        if (a_tr) {   // row = k index inside the tile (16 chunks of 8 m per row); rows and columns past the matrix are the plane's zero padding
+            const int rt = q >> 4, ct = q & 15;
+            goffA[it] = 2u * (unsigned)(rt * g.lda + m0 + 8 * (ct ^ (((rt & 3) << 2) | ((rt >> 2) & 3))));
+        }
     }
 #pragma unroll
     for (int it = 0; it < NB1; ++it) {
@@ -420,6 +431,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
             }
         } else {
+            if constexpr (ATR) {
+                if (a_tr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    // lane i of a 16-lane group supplies the address of row q = i >> 2, columns 4 (i & 3) .. + 3 of a 4-row block and
+                    // receives column i of the four rows: two blocks (k = 32 ks + 8 slot + 0..3, + 4..7) are a lane's 8 k
+                    typedef short v4s __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) v4s* lds_v4s;
+                    const int q = l15 >> 2, pp = l15 & 3;
+                    const unsigned char* tb = smem + buf * A_BYTES;
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        uint32_t w[4];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int row = 32 * ks + 8 * slot + 4 * h + q;
+                            const int key = (q << 2) | ((2 * slot + h) & 3);
+                            const int ch = (2 * (wm * TM + mi) + (pp >> 1)) ^ key;
+                            const v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 256 * row + 16 * ch + 8 * (pp & 1)));
+                            w[2 * h] = ((const uint32_t*)&r)[0]; w[2 * h + 1] = ((const uint32_t*)&r)[1];
+                        }
+                        f[mi] = u32x4{w[0], w[1], w[2], w[3]};
+                    }
+#endif
+                    return;
+                }
+            }
             const unsigned char* c = smem + (bsh ? buf * A_BYTES : buf * STAGE) + (wm * WM + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
@@ -933,6 +970,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 TileRef ra2 = walk_ref(w);
                 TileRef rb = ra0;                                // (B of the position: all three pieces)
                 rb.npb = 3;
+                // (a_tr: a k position is 64 ROWS of the row-major A plane, not 128 bytes along a row)
+                const uint32_t astep = a_tr ? 128u * (uint32_t)g.lda : 128u;
+                if (a_tr) { const uint32_t fix = (astep - 128u) * (uint32_t)w.b; ra0.oa += fix; ra1.oa += fix; ra2.oa += fix; }
                 dma_part(0, ra0, 1); dma_part(0, rb, 2);         // A0(0) -> A stage 0, B(0) -> B stage 0
                 dma_part(1, ra1, 1);                             // A1(0) -> A stage 1
                 __builtin_amdgcn_s_waitcnt(vm(NA));              // A0(0), B(0) have landed
@@ -944,7 +984,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     KURBM_LSTAMP(0);
                     // ---- T0(kt) in work
                     dma_part(sa, ra2, 1);                        // A2(kt)
-                    ra0.oa += 128u; ra1.oa += 128u; ra2.oa += 128u; rb.ob += 128u;   // -> position kt + 1
+                    ra0.oa += astep; ra1.oa += astep; ra2.oa += astep; rb.ob += 128u;   // -> position kt + 1
                     if (more) {
                         dma_part((kt + 1) & 1, rb, 2, 0, 0, 0, 0, 2);               // B0, B1(kt + 1)
                         KURBM_LSTAMP(1);
@@ -1937,6 +1977,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 if (gr < g.M && gc < g.ldo_cols)
                     *reinterpret_cast<u32x4*>(plane + (size_t)gr * g.ldo + gc) =
                         *reinterpret_cast<const u32x4*>(smem + row * PROW16 + 16 * c);
+                else if (gr < g.out_rows_pad && gc < g.ldo_cols)      // (rows past the batch that a k = batch consumer will read: zeros)
+                    *reinterpret_cast<u32x4*>(plane + (size_t)gr * g.ldo + gc) = u32x4{0u, 0u, 0u, 0u};
             }
         }
     }
@@ -2079,6 +2121,7 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
         }
         if (ok && np >= 1 && np < g.nseg) { g.bshare2 = 1; g.bsh_np = np; }
     }
+    if (g.a_tr && !(g.bshare == 2 && epi == EPI_SLAB)) return hipErrorInvalidValue;   // (only that walk reads a row-major A operand)
     g.walk3 = (epi == EPI_SLAB && g.pb_max == 3 && g.f8pos && g.nseg == 2 && ((g.seg_codes >> 7) & 3u) == 3u &&
                g.kt_per_split % 3 == 0 && g.kt_total % 3 == 0) ? 1 : 0;
     {   // the block mapping's divisors as multiply-high constants: exact while dividend x divisor < 2^32 (every grid of the
