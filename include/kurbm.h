@@ -117,12 +117,10 @@ void kurbm_ctx_destroy(kurbm_ctx* ctx);
  * live context.  -1 = automatic where a knob has an automatic setting.  No production caller needs it. */
 int kurbm_ctx_set_option(kurbm_ctx* ctx, const char* name, int value);
 /* Sticky status bits of the context's kernels, read back from the device (THIS call synchronises with the device; the
- * others never do) and cleared.  Bit 0: a workgroup of the statistics GEMM of kurbm_cd_step_x3 / _bf16 -- which reduces
- * its own split-K slabs when its whole grid is resident, one workgroup per CU -- gave up waiting for the other k-slices of
- * its tile (0.2 s), i.e. the grid was NOT resident (a CU mask, a device shared with a kernel that never ends): that
- * step's update of W is incomplete.  That in-launch reduction is OFF by default (knob KURBM_X3_FUSED, default 0: the separate
- * slab-reduce launch runs, which cannot time out); with KURBM_X3_FUSED=1 the bit has been 0 in every run this build has seen,
- * and the host classes read it at the end of every fit() / epoch call and raise before training goes on. */
+ * others never do) and cleared.  Every device-side wait in this library is bounded; a wait that runs into its bound sets a bit
+ * here and SKIPS its work instead of hanging the GPU.  Bit 1: the peer exchange (kurbm_peer_*) gave up waiting for a rank's flag.
+ * Bit 2: the grid barrier of kurbm_cd_step_small timed out -- its grid was not resident (a CU mask, a device shared with a kernel
+ * that never ends).  0 in every run this build has seen; the host classes read it at the end of every fit() and raise. */
 int kurbm_ctx_status(kurbm_ctx* ctx, int* bits);
 
 /* ---- RNG test hook: out[r, c] = u(row0 + r, c) under the contract above -------- */

@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_X3_FUSED, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_BSHARE, KN_X3_PAIR, KN_X3_SPLIT_STATS, KN_X3_ATR,
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_PAIR, KN_X3_SPLIT_STATS, KN_X3_ATR,
        KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
@@ -36,17 +36,14 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_UNFUSED_MIRROR", 0},   // 1: slab reduce and weight-piece mirror as two launches
     {"KURBM_X3_XCD2D", 1},         // 0: linear block order of k_gemm_pb instead of one 2-D block of tiles per XCD
     {"KURBM_REDUCE_TR", 0},        // tile height (16 / 32 / 64) of the slab-reduce + mirror launch; 0: by the grid it makes
-    {"KURBM_X3_FUSED", 0},         // 1: the statistics GEMM reduces its own split-K slabs where its grid is resident (bit-identical to the
-                                   //    separate reduce launch and no faster: 117.7 against 117.5 us per step)
     {"KURBM_DP_CHUNKS", 0},        // row ranges of dW in the data-parallel step when the caller passes n_chunks <= 0; 0: by message size
     {"KURBM_ANYORDER", 0},         // TIMING ONLY (results race): bit 0 the half steps, bit 1 the statistics GEMM are launched without
                                    // the AQL barrier bit -- the upper bound of what overlapping dependent launches could gain
     {"KURBM_X3_STATS_BYTES", 1},   // 0: v_neg^T reaches the statistics GEMM as a bf16 plane (1: as bytes where the positive half is fp8)
     {"KURBM_MAP_SLOW", 0},         // 1: k_gemm_pb maps its blocks by integer division (the path of grids too large for the multiply-high
                                    //    constants: tests)
-    {"KURBM_X3_BSHARE", 1},        // 0: the three segments of a real-valued A operand one after the other, each staging its own B pieces
-    {"KURBM_X3_PAIR", 1},          // 0: a real-valued A operand walks three tiles per k position on 256 x 64 tiles (round 3); 1: two tiles per
-                                   //    position on 128 x 128 tiles (k_gemm_pb, "BSP")
+    {"KURBM_X3_PAIR", 1},          // 0: a real-valued A operand walks its three segments one after the other (256 x 64 tiles, the generic walk);
+                                   //    1: two tiles per k position on 128 x 128 tiles (k_gemm_pb, "BSP")
     {"KURBM_X3_SPLIT_STATS", 1},   // 0: the statistics of real-valued data in ONE launch (round 3: three one-piece positive tiles per k position);
                                    //    1: two launches -- the positive half as the transposed problem h_pos^T (bytes) x the pieces of v_pos^T, the
                                    //    negative half on byte planes (Bernoulli visibles) or on the paired walk (Gaussian visibles)
@@ -694,7 +691,6 @@ static Mirror carve_mirror(const kurbm_ctx* ctx, void* base, int n_vis, int n_hi
 struct WorkspaceB {
     uint16_t *vb, *vbT, *hb, *hbT, *v2b, *v2bT, *h2b, *hnT, *cb;
     float *part_h, *part_v, *slab, *tmp32;
-    unsigned* sync;     // SYNC_WORDS arrival counters of the fused slab reduction (one per output tile of the statistics)
     float* rowpart;     // kurbm_score_x3's row partials
     int Kv, Kh, Kb, Lv, Lh, Lb, ldh32, ldv32, max_row_tiles;   // K*: k extents; L*: leading dimensions of the bf16 planes
     size_t planeV, planeVT, planeHT;   // distance between the pieces of v_pos (both images) and of h_neg^T
@@ -702,7 +698,6 @@ struct WorkspaceB {
 };
 
 struct OuterPlanB { int gm, gn, nkt, kt_total, nsplit, nsplit_bound, kt_per_split, ld_slab, cfg; };
-constexpr int SYNC_WORDS = 1024;   // >= the CUs of any gfx950 part: a fused statistics grid has at most one tile per CU
 
 // the statistics GEMM on k_gemm_pb: k-tile 64, one workgroup per CU, nseg segments walked fastest, so a slice is a whole
 // number of k positions
@@ -811,7 +806,6 @@ static WorkspaceB carve_bf16(const kurbm_ctx* ctx, void* base, int rows, int n_v
     }
     w.slab = take32(w.slab_stride * nslab_res);
     w.tmp32 = take32((size_t)rows * (w.ldh32 > w.ldv32 ? w.ldh32 : w.ldv32));       // fp32 plane for the test hook
-    w.sync = reinterpret_cast<unsigned*>(take32(SYNC_WORDS));
     // the score of fit(verbose = 1): softplus row partials of F(v) and F(v') per 64-column tile, |F - F'| per row
     w.rowpart = take32((size_t)(2 * ceil_div(n_hid, 64) + 1) * round_up(rows, 4));
     w.bytes = off;
@@ -853,7 +847,6 @@ struct HalfOutB {
     float* colpart = nullptr; int ld_colpart = 0;
     float colsign = 1.f;                                  // x3: colpart = colsign * column sums of the value plane
     int* grid_m_out = nullptr;
-    unsigned* zero_words = nullptr; int n_zero = 0;       // words this launch zeroes (the next launch's arrival counters)
     float* rowpart = nullptr; int ld_rowpart = 0;         // x3, Bernoulli draws: softplus row sums of the tile's columns (the score)
     int* grid_n_out = nullptr;                            // ... and how many column tiles wrote them
 };
@@ -876,9 +869,9 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.pb_max = m.pieces;
         // a real-valued A operand: its three segments per k position, so that they can share one staging of the B pieces
         // (k_gemm_pb, "BSH"; launch_gemm_pb checks the pattern)
-        if (g.nseg == 3 && ctx->knob[KN_X3_BSHARE]) { g.seg_fastest = 1; g.inv_nseg = inv_of(3); }
-        // ... and on 128 x 128 tiles as TWO tiles per k position (the paired walk): the tile count, not the bytes, sets that loop's time
-        const bool pair = g.nseg == 3 && g.seg_fastest && m.pieces == 3 && ctx->knob[KN_X3_PAIR] != 0;
+        // (k_gemm_pb, "BSP"; launch_gemm_pb checks the pattern) on 128 x 128 tiles as TWO tiles per k position: the paired walk
+        const bool pair = g.nseg == 3 && m.pieces == 3 && ctx->knob[KN_X3_PAIR] != 0;
+        if (pair) { g.seg_fastest = 1; g.inv_nseg = inv_of(3); }
         g.pair_ok = pair ? 1 : 0;
         g.a_bytes = a_bytes ? 1 : 0;   // (a byte plane of 0/1 values: one piece, lda bytes between its rows)
         g.cfg = 0;
@@ -905,7 +898,6 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.outT_neg = o.outT_neg ? 1 : 0; g.outT_f8 = o.outT_b8 ? 2 : o.outT_f8 ? 1 : 0;
         g.out_f32 = o.out_f32; g.prob_f32 = o.prob_f32; g.out_u = o.out_u; g.ldo32 = o.ldo32;
         g.colpart = o.colpart; g.ld_colpart = o.ld_colpart; g.colsign = o.colsign;
-        g.zero_words = o.zero_words; g.n_zero = o.n_zero;
         if (o.rowpart) {
             g.rowpart = o.rowpart; g.ld_rowpart = o.ld_rowpart; g.rp = 1;
             if (o.grid_n_out) *o.grid_n_out = ceil_div(g.N, g.cfg == 2 ? 64 : 128);   // (tiles in the column padding write zeros)
@@ -1117,23 +1109,15 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
                               : plf;
     const size_t slab_stride = sub ? (size_t)Mr * pl.ld_slab : w.slab_stride;
     const bool ap = o->apply != 0;
-    // FUSED reduction: the statistics GEMM sums its own split-K slabs, applies lr * dW and rewrites the weight-piece mirror
-    // (kurbm_x3.hip) -- no k_reduce_apply_split launch.  Only where every workgroup of its grid is resident at once (one
-    // per CU: the k-slices of a tile wait for each other) and the step applies its update in place; the data-parallel,
-    // emit-only, row-range and `which`-restricted forms keep the separate launch.
     // (a row range [m_lo, m_hi) of the visible units: each half may use half of the slabs carved for the whole matrix)
     const SplitStats sps0 = plan_split_stats(ctx, rows, p->n_vis, p->n_hid, gauss);
     const SplitStats sps = sub ? plan_split_stats(ctx, rows, Mr, p->n_hid, gauss,
                                                   (int)((w.slab_stride * (size_t)(sps0.neg.nsplit_bound + sps0.pos.nsplit_bound)) / ((size_t)Mr * sps0.pos.ld_slab) / 2))
                                : sps0;
-    const bool fuse = ctx->knob[KN_X3_FUSED] != 0 && !ctx->knob[KN_UNFUSED_MIRROR] && need_w && ap && (which & 1) && !o->delta_out &&
-                      !sub && !split_stats && (only < 0 || only == 4) && pl.gm * pl.gn * pl.nsplit <= ctx->ncu && pl.gm * pl.gn <= SYNC_WORDS &&
-                      (size_t)pl.nsplit * slab_stride * 4 < 0x7FFFFFFFull;
     // h_neg = sigmoid(v_neg.W + b_h), probabilities (rbm.py:124): only its transposed image is needed, and only by the
     // statistics GEMM, where it enters with a minus sign: it is stored as -h_neg
     if (KURBM_STAGE(3)) {
         HalfOutB ho;
-        if (fuse) { ho.zero_words = w.sync; ho.n_zero = pl.gm * pl.gn; }   // (the arrival counters of the launch that follows)
         ho.outT = w.hnT; ho.ldoT = w.Lb; ho.outT_pieces = pieces; ho.outT_plane = w.planeHT; ho.outT_neg = true;
         ho.colpart = w.part_h + (size_t)2 * ceil_div(rows, 128) * w.ldh32; ho.ld_colpart = w.ldh32; ho.colsign = -1.f;
         ho.grid_m_out = &gm_h;
@@ -1233,21 +1217,14 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.pb_max = pieces;
         g.seg_fastest = 1; g.inv_nseg = inv_of(g.nseg);
         if (f8pos) { g.f8pos = 1; g.inv_nseg = inv_of(2 * g.nseg - 1); }   // (tiles per 128-deep unit)
-        g.bshare_ok = ctx->knob[KN_X3_BSHARE];
         g.m_fastest = ctx->knob[KN_X3_STATS_MFAST];
         g.cfg = pl.cfg;
         g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
         g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
         g.xcd2d = ctx->knob[KN_X3_XCD2D]; g.map_force = ctx->knob[KN_MAP_SLOW];
         g.any_order = (ctx->knob[KN_ANYORDER] >> 1) & 1;
-        if (fuse) {
-            g.fuse = 1; g.sync = w.sync; g.status = ctx->status; g.red = a;
-            // (a launch replayed alone, kurbm_cd_step_x3_stage: no half step in front has zeroed the counters)
-            if (only == 4) HIP_TRY(hipMemsetAsync(w.sync, 0, (size_t)pl.gm * pl.gn * sizeof(unsigned), st));
-        }
         HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
     }
-    if (fuse) return KURBM_OK;   // W, the biases and the mirror have been written by the statistics launch
     if (mirror_in_reduce) {
         if (KURBM_STAGE(5)) HIP_TRY(launch_reduce_apply_split(a, st));
         if (only == 6)

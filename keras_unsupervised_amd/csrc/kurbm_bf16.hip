@@ -177,15 +177,41 @@ __device__ __forceinline__ void reduce_apply_split_body(ReduceArgs& a, int tiles
                 }
             }
         };
+        // Every load of the thread's TR / 16 rows goes out before the first sum: the rows' weights and their first four slabs (this launch
+        // is a burst of ~17 MB of loads that every CU must keep in flight: with the rows one after the other a wave held 5 x 16 bytes per
+        // lane in flight, now TR / 16 times that).  The slabs are still added in slab order, row by row: the same bits as before.
+        constexpr int NJ = TR / 16;
+        f32x4 wv[NJ], sv[NJ][4];
+        bool live[NJ];
 #pragma unroll
-        for (int j = 0; j < TR / 16; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int r = by * TR + rq + 16 * j;
-            f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            if (r < a.n_vis && c < a.n_hid) {
-                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            live[j] = r < a.n_vis && c < a.n_hid;
+            wv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int z = 0; z < 4; ++z) sv[j][z] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (live[j]) {
+                if (a.W) wv[j] = *reinterpret_cast<const f32x4*>(a.W + (size_t)r * a.ldw + c);           // ldw % 4 == 0
                 if (a.slab) {
                     const float* sp = a.slab + (size_t)r * a.ld_slab + c;    // ld_slab % 4 == 0: the group stays inside the row
-                    int zz = 0;
+#pragma unroll
+                    for (int z = 0; z < 4; ++z)
+                        if (z < a.nslab) sv[j][z] = *reinterpret_cast<const f32x4*>(sp + (size_t)z * a.slab_stride);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = by * TR + rq + 16 * j;
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (live[j]) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                if (a.slab) {
+                    const float* sp = a.slab + (size_t)r * a.ld_slab + c;
+#pragma unroll
+                    for (int z = 0; z < 4; ++z)
+                        if (z < a.nslab) s += sv[j][z];
+                    int zz = 4;
                     for (; zz + 4 <= a.nslab; zz += 4) {
                         const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 0) * a.slab_stride);
                         const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + (size_t)(zz + 1) * a.slab_stride);
@@ -196,8 +222,8 @@ __device__ __forceinline__ void reduce_apply_split_body(ReduceArgs& a, int tiles
                     for (; zz < a.nslab; ++zz) s += *reinterpret_cast<const f32x4*>(sp + (size_t)zz * a.slab_stride);
                 }
                 if (a.W) {
-                    float* wp = a.W + (size_t)r * a.ldw + c;                  // ldw % 4 == 0
-                    w = *reinterpret_cast<const f32x4*>(wp);
+                    float* wp = a.W + (size_t)r * a.ldw + c;
+                    w = wv[j];
                     if (a.slab) w = w + s * a.lr;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)

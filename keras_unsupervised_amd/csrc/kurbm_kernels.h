@@ -213,8 +213,6 @@ struct GemmArgsB {
     const uint16_t* baseB;
     size_t a_plane0, a_plane1, b_plane0, b_plane1;
     unsigned long long seg_codes;
-    // EPI_HALFSTEP: workgroup 0 stores n_zero zeros here (the arrival counters of the statistics GEMM that follows)
-    unsigned* zero_words;
     uint32_t inv_nkt;     // floor(2^32 / nkt) + 1: segment of k-tile t = umulhi(t, inv_nkt)
     uint32_t inv_nseg;
     uint32_t offB0, offB1;
@@ -228,7 +226,6 @@ struct GemmArgsB {
     // (8 / (xcd_r xcd_c)) x xcd_r x xcd_c grid over (k slices, row tiles, column tiles); each takes one block of it, so the A
     // rows and B rows it pulls through its own L2 are a fraction of the matrix instead of all of one operand
     int xcd_r, xcd_c;
-    int n_zero;
     // k_gemm_pb (kurbm_x3.hip) reads the code as: bits 0-1 ia, bits 2-3 npb = number of B pieces
     // (0 .. npb-1) multiplied with that A tile, bit 4 set; and may walk the segments FASTEST
     // (t = k-tile * nseg + segment), so that every split-K slice gets the same mix of light and heavy tiles
@@ -244,12 +241,8 @@ struct GemmArgsB {
     int grid_m, grid_n;
     int m_fastest;
     int a_bytes;          // the A operand is such a byte plane (lda bytes between its rows; one segment): k_gemm_pb<..., AB>
-    int bshare;           // (launcher) a real-valued A operand on three-piece weights: segments (A piece p) x (B pieces 0 .. 2 - p), walked
-                          // segment-fastest -- the three tiles of a k position share ONE staging of its B pieces (k_gemm_pb, "BSH");
-                          // 2: ... as TWO tiles per position on 128 x 128 tiles (the paired walk, "BSP")
-    int bshare2;          // (launcher) statistics GEMM of real-valued data: per k position `bsh_np` positive segments (A piece p of set 0 x B
-    int bsh_np;           // piece 0 of set 0) and then the negative ones (set 1, first with three B pieces): the tiles of a k position share
-                          // one staging of the position's B pieces -- 1 + 3 -- and the A tiles ring through three stages (k_gemm_pb, "BSH2")
+    int bshare;           // (launcher) 2: the PAIRED walk -- a real-valued A operand on three-piece B rows, segments (A piece p) x (B pieces
+                          // 0 .. 2 - p) walked segment-fastest, as TWO tiles per k position on 128 x 128 tiles (k_gemm_pb, "BSP"); 0: not
     int map_slow;         // (launcher) 1: the block mapping divides (a grid too large for the multiply-high constants)
     int walk3;            // (launcher) f8pos with ONE other segment of three pieces: the tiles go fp8, 3-piece, 3-piece, ... in whole
                           // units per k slice, and both loops of the statistics kernel step through that pattern instead of decoding a tile list
@@ -294,7 +287,6 @@ struct GemmArgsB {
     int ld_slab;
     int slab_t;           // EPI_SLAB on a byte-plane A operand (k_gemm_pb "ABP"): the tile leaves TRANSPOSED -- M counts the slab's COLUMNS,
                           // N its rows (the positive statistics of real-valued data as h_pos^T x the pieces of v_pos^T)
-    int bshare_ok;        // caller: the statistics GEMM may share B stagings between the tiles of a k position (ctx knob KURBM_X3_BSHARE)
     int a_tr;             // caller (paired walk of the statistics GEMM): A0 is a ROW-MAJOR plane [k][M], lda its leading dimension -- the
                           // tiles are staged as [k][m] and read by transposed LDS reads (k_gemm_pb, "ATR")
     int pair_ok;          // caller: a real-valued A operand on 128 x 128 tiles may walk two tiles per k position (ctx knob KURBM_X3_PAIR; bshare = 2)
@@ -305,14 +297,6 @@ struct GemmArgsB {
     float* rowpart;
     int ld_rowpart;
     int rp;               // EPI_HALFSTEP (Bernoulli draws, x3): 1 = also write those row partials (k_gemm_pb<..., RP>)
-    // EPI_SLAB with fuse != 0: the statistics GEMM reduces its own split-K slabs (kurbm_x3.hip, "fused reduction"): `red`
-    // names W, lr, the weight-piece mirror and the bias partials exactly as the separate launch (k_reduce_apply_split) takes
-    // them; `sync` = one arrival counter per output tile [grid_m * grid_n], ZERO when the launch starts (the half step in
-    // front zeroes them: zero_words); `status` = a sticky word of the context, bit 0 set if a workgroup gave up waiting
-    int fuse;
-    unsigned* sync;
-    unsigned* status;
-    ReduceArgs red;
     // diagnostic build only (KURBM_STAMPS): 8 x u64 per workgroup (k_gemm_pb)
     unsigned long long* stamps;
 };

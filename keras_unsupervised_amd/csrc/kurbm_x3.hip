@@ -27,8 +27,9 @@
 //   (ABP: template slot RP on EPI_SLAB)  the tile leaves transposed into ordinary slabs), the negative half on bytes or on BSP
 //   one-piece tiles (rounded bf16)     128 x 128, four B stages + three A blocks, tiles requested four ahead, fragments read a tile
 //                                      ahead across the barrier (DEEP)
-//   older walks kept behind knobs      BSH / BSH2 (three tiles per k position sharing one B staging: KURBM_X3_PAIR=0 /
-//                                      KURBM_X3_SPLIT_STATS=0), the generic two-stage walk of a tile list (ragged shapes)
+//   everything else                    the generic two-stage walk of a tile list (segments of one to three pieces: KURBM_X3_PAIR=0,
+//                                      KURBM_X3_SPLIT_STATS=0, the free-energy GEMM of real-valued data, fp8 positive statistics on
+//                                      bf16 planes)
 // Entry: the argument segment warmed in one batch (kurbm_device.h), block mapping by multiply-high constants into XCD-aware 2-D
 // blocks, the loaders at high priority until their first requests are out.
 //
@@ -91,26 +92,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define KURBM_DEEP_FENCE 1   // the deep schedule's barrier: 1 = __syncthreads (every fragment read has RETURNED), 0 = bare s_barrier
 #endif
 
-// Fused reduction of the statistics GEMM: the rows [lo, hi) of its tile (tile-relative, multiples of 4) that k-slice z reduces
-// -- an even share of the tile's rows that lie inside the matrix, so the last row tile of 784 = 3 x 256 + 16 visible units
-// gives each of its slices 4 rows, not one of them 16.
 // x / d through the launcher's ceil(2^32 / d) (x, d < 2^16: exact; inv == 0 stands for d = 1)
 __device__ __forceinline__ int div_magic(int x, uint32_t inv) { return inv ? (int)__umulhi((uint32_t)x, inv) : x; }
 // (slow = 1: a grid beyond the constants' exact range -- launch_gemm_pb -- pays for the division)
 __device__ __forceinline__ int div_map(int x, int d, uint32_t inv, int slow) { return slow ? x / d : div_magic(x, inv); }
-
-struct FuseRows { int lo, hi; };
-__device__ __forceinline__ FuseRows fuse_rows(const GemmArgsB& g, int m0, int z) {
-    int valid = g.M - m0;
-    const int bm_rows = (g.cfg == 2) ? 256 : 128;
-    if (valid > bm_rows) valid = bm_rows;
-    if (valid < 0) valid = 0;
-    const int per = ((valid + g.nsplit - 1) / g.nsplit + 3) & ~3;
-    FuseRows r;
-    r.lo = z * per < valid ? z * per : valid;
-    r.hi = r.lo + per < valid ? r.lo + per : valid;
-    return r;
-}
 
 // Wave-specialised: four LOADER waves beside the eight MFMA waves (768 threads, three waves per SIMD).  The loaders do all
 // the staging in a loop of their own -- LDS-DMA, `buffer_load_dwordx4 ... lds`: no register and no ds_write between memory
@@ -184,11 +169,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // (byte-plane statistics: three A blocks, a B stage for each of the two 3-piece tiles of a unit and one PIECE for its fp8 tile)
     constexpr int STAGES_BYTES = ABS ? NAB * A_BYTES + 2 * B_BYTES + B1_BYTES
                                : AB ? NAB * A_BYTES + NSTG * B_BYTES : NSTG * (A_BYTES + B_BYTES);
-    // BSH (g.bshare; non-AB three-piece half steps: a real-valued A operand): THREE A stages and two B stages -- the three tiles
-    // of a k position (A piece 0 x B pieces 0-2, piece 1 x 0-1, piece 2 x 0) share one staging of that position's B pieces:
-    // 120 instead of 144 KB per k position, and the third A stage lets a counted vmcnt keep a tile in flight across the barrier
-    // (with two [A | B] stages the loaders waited for the tile they had just requested: issue + landing = the tile's time).
-    constexpr bool BSH = !AB && PB == 3 && EPI == EPI_HALFSTEP;
     // BSP (g.bshare == 2; 128 x 128 tiles only): the PAIRED walk of a real-valued A operand -- per k position TWO tiles of 48 MFMAs per
     // wave each, (A piece 0) x (B pieces 0-2) and then (piece 1) x (0-1) together with (piece 2) x (0) -- instead of three tiles of
     // 48 / 32 / 16: a tile costs its barrier and its restart whatever is in it (one-piece tiles of 512 matrix-pipe
@@ -196,27 +176,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // beside the two B stages: 160 KB.  The half steps on grey-level data / Gaussian visibles, and the negative statistics of
     // Gaussian visibles (EPI_SLAB) walk it.
     constexpr bool BSP = (BM == 128) && !AB && PB == 3 && (EPI == EPI_HALFSTEP || EPI == EPI_SLAB);
-    constexpr int BSH_NA = (BM == 128) ? 4 : 3;          // A stages of the shared-B layouts
-    constexpr int BSH_BYTES = BSH_NA * A_BYTES + 2 * B_BYTES, BSH_BOFF = BSH_NA * A_BYTES;
+    constexpr int BSP_BYTES = 4 * A_BYTES + 2 * B_BYTES, BSP_BOFF = 4 * A_BYTES;
     constexpr int SMEM_BYTES00 = (STAGES_BYTES > PATCH_BYTES) ? STAGES_BYTES : PATCH_BYTES;
-    constexpr int SMEM_BYTES0 = (BSP && BSH_BYTES > SMEM_BYTES00) ? BSH_BYTES : SMEM_BYTES00;
-    // BSH2 (g.bshare2; the statistics GEMM of real-valued data): the same ring of three A stages; a B stage holds the k position's
-    // positive piece and its three negative pieces (four piece slots)
-    constexpr int BSH2_BYTES = 3 * A_BYTES + 2 * 4 * B1_BYTES;
-    constexpr bool BSH2 = !AB && PB == 3 && EPI == EPI_SLAB && BSH2_BYTES <= 160 * 1024;
-    constexpr int SMEM_BYTES1 = (BSH && BSH_BYTES > SMEM_BYTES0) ? BSH_BYTES : SMEM_BYTES0;
-    constexpr int SMEM_BYTES = (BSH2 && BSH2_BYTES > SMEM_BYTES1) ? BSH2_BYTES : SMEM_BYTES1;
+    constexpr int SMEM_BYTES = (BSP && BSP_BYTES > SMEM_BYTES00) ? BSP_BYTES : SMEM_BYTES00;
     // the Philox words of each lane's first NI_LDS output columns are drawn in the prologue (the MFMA waves idle there
     // until the first tile has landed) and wait in LDS behind the stage buffers, 16 bytes per lane and 4-row group
-    // (none beside the BSH layout: 144 of the 160 KB)
-    constexpr int NI_LDS = (EPI == EPI_HALFSTEP && NOISE == NOISE_BERNOULLI && !BSH) ? 1 : 0;
+    // (none beside the paired walk's layout: all 160 KB)
+    constexpr int NI_LDS = (EPI == EPI_HALFSTEP && NOISE == NOISE_BERNOULLI && !BSP) ? 1 : 0;
     constexpr int DRAW_LDS_BYTES = NI_LDS * TM * NT * 16;
-    // EPI_SLAB, fused reduction: behind the fp32 patch of the tile sit a chunk of FUSE_RC x BN new weights (transposed mirror
-    // stores) and the word through which the polling lane tells the workgroup whether all slices of the tile arrived
-    constexpr int FUSE_RC = 4096 / BN;                                       // rows per chunk: 1024 float4 = 2 per MFMA thread
-    constexpr int FUSE_TILE_OFF = (BM * PROW32 + 255) / 256 * 256, FUSE_TILE_ROW = BN + 1;
-    constexpr int FUSE_FLAG_OFF = FUSE_TILE_OFF + FUSE_RC * FUSE_TILE_ROW * 4;
-    static_assert(EPI != EPI_SLAB || FUSE_FLAG_OFF + 16 <= SMEM_BYTES, "fused reduction: scratch behind the patch");
     static_assert(SMEM_BYTES + DRAW_LDS_BYTES <= 160 * 1024, "LDS per workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES + DRAW_LDS_BYTES];
 
@@ -419,10 +386,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     const int swz = (l15 >> 1) & 7;
     // AB: `ablk` = the block buffer (0 / 1) of the tile pair in work; tile `buf` (= its parity) is half `buf` of the block's k
     int ablk = 0;
-    const bool bsh2 = BSH2 && g.bshare2 != 0;
-    const bool bsp = BSP && g.bshare == 2;
-    const bool bsh = (BSH && g.bshare != 0) || bsh2 || bsp;   // (wave-uniform; BSH: the stage arguments are compile-time constants at every call)
-    const int bsh_bstride = bsh2 ? 4 * B1_BYTES : B_BYTES;   // (a B stage: the three pieces; BSH2: four piece slots)
+    const bool bsp = BSP && g.bshare == 2;     // (wave-uniform) the paired walk: A stages and B stages apart
     auto frag_a = [&](int buf, int ks, afrag (&f)[TM], int blk_step = 0) __attribute__((always_inline)) {
         if constexpr (AB) {   // tile `buf` of the block, lane group `slot`: chunk 4 buf + slot of the 128-byte row (k-permuted plane)
             if (ks == 0) {
@@ -457,13 +421,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     return;
                 }
             }
-            const unsigned char* c = smem + (bsh ? buf * A_BYTES : buf * STAGE) + (wm * WM + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
+            const unsigned char* c = smem + (bsp ? buf * A_BYTES : buf * STAGE) + (wm * WM + l15) * ROWB + 16 * ((4 * ks + slot) ^ swz);
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) f[mi] = *reinterpret_cast<const u32x4*>(c + mi * 16 * ROWB);
         }
     };
     auto frag_b = [&](int buf, int ks, int p, u32x4 (&f)[TN]) __attribute__((always_inline)) {
-        const unsigned char* c = smem + (bsh ? BSH_BOFF + buf * bsh_bstride : buf * STAGE + B_OFF) + p * B1_BYTES + (wn * WN + l15) * ROWB +
+        const unsigned char* c = smem + (bsp ? BSP_BOFF + buf * B_BYTES : buf * STAGE + B_OFF) + p * B1_BYTES + (wn * WN + l15) * ROWB +
                                  16 * ((4 * ks + slot) ^ swz);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) f[ni] = *reinterpret_cast<const u32x4*>(c + ni * 16 * ROWB);
@@ -502,9 +466,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
     // (cur = the tile's B stage; half = its half of the A block, AB only -- with two stages the two coincide)
     // (bcur / anext_ / bnext_ >= 0: the B stage of this tile and the A / B stages of the next one, where they are not `cur` and
     //  `cur + 1` -- the shared-B walk)
-    //  pb0 / pb0n: the piece slot of this tile's / the next tile's piece 0 in its B stage (BSH2))
     auto one_tile = [&](const int cur, const int half, auto npb_tag, const int bcur_ = -1, const int anext_ = -1,
-                        const int bnext_ = -1, const int pb0 = 0, const int pb0n = 0) __attribute__((always_inline)) {
+                        const int bnext_ = -1) __attribute__((always_inline)) {
         const int acur = AB ? half : cur, anext = anext_ >= 0 ? anext_ : AB ? (half ^ 1) : (cur + 1) % NSTG;
         const int bcur = bcur_ >= 0 ? bcur_ : cur, bnext = bnext_ >= 0 ? bnext_ : (cur + 1) % NSTG;
         constexpr int NPB = decltype(npb_tag)::value;
@@ -520,10 +483,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             if constexpr (NPB == 3) {
                 // fragments are read TWO micro-steps ahead (an LDS read under load takes longer than the 8 MFMAs
                 // of one micro-step); the tile is entered with fa[0], fb[0] loaded, so u = 0 catches up
-                if (u == 0) { frag_b(bcur, 0, pb0 + 1, fb[1]); frag_b(bcur, 0, pb0 + 2, fb[2]); }
-                if (u == 1) { frag_a(acur, 1, fa[1]); frag_b(bcur, 1, pb0, fb[0]); }
-                if (u == 2) frag_b(bcur, 1, pb0 + 1, fb[1]);
-                if (u == 3) frag_b(bcur, 1, pb0 + 2, fb[2]);
+                if (u == 0) { frag_b(bcur, 0, 1, fb[1]); frag_b(bcur, 0, 2, fb[2]); }
+                if (u == 1) { frag_a(acur, 1, fa[1]); frag_b(bcur, 1, 0, fb[0]); }
+                if (u == 2) frag_b(bcur, 1, 1, fb[1]);
+                if (u == 3) frag_b(bcur, 1, 2, fb[2]);
 #ifndef KURBM_BARRIER_AT
 #define KURBM_BARRIER_AT 5
 #endif
@@ -540,7 +503,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #endif
                 if (u == KURBM_NEXT_READ_AT) {
                     frag_a(anext, 0, fa[0], acur);   // (AB: after the second tile of a pair comes the other block)
-                    frag_b(bnext, 0, pb0n, fb[0]);
+                    frag_b(bnext, 0, 0, fb[0]);
                 }
                 mfmas(fa[ks & 1], fb[u % 3]);
                 if (KURBM_BARRIER_AT == 3 && u == 3) {
@@ -561,12 +524,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             if (u + 1 < NU) {
                 const int ksn = (u + 1) / NPB, pn = (u + 1) % NPB;
                 if (pn == 0) frag_a(acur, ksn, fa[ksn & 1]);
-                frag_b(bcur, ksn, pb0 + pn, fb[(u + 1) & 1]);
+                frag_b(bcur, ksn, pn, fb[(u + 1) & 1]);
             } else {
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
                 frag_a(anext, 0, fa[0], acur);   // (AB: after the second tile of a pair comes the other block)
-                frag_b(bnext, 0, pb0n, fb[0]);
+                frag_b(bnext, 0, 0, fb[0]);
             }
             mfmas(fa[ks & 1], fb[u & 1]);
             if (AB && (u + 1) % NPB == 0) {
@@ -687,7 +650,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         if (nt > 0) {
             // part: bit 0 = the A tile (AB: pieces [a_lo, a_hi) of A block `ablk_`, whose k offset is r.oa), bit 1 = the B pieces
             auto dma_part = [&](int buf, const TileRef& r, int part, int ablk_ = 0, int a_lo = 0, int a_hi = 1 << 20, int pb_lo = 0,
-                                int pb_hi = PB, int pb_dst = 0) __attribute__((always_inline)) {
+                                int pb_hi = PB) __attribute__((always_inline)) {
 #if defined(KURBM_ABLATE) && (KURBM_ABLATE & 1)
                 return;   // timing-only build: no global loads
 #endif
@@ -701,7 +664,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 typedef __attribute__((address_space(3))) void* lds_ptr;
                 const int lw = wave - NT / 64;
                 if (part & 1) {
-                    unsigned char* a = smem + (AB ? ablk_ * A_BYTES : bsh ? buf * A_BYTES : buf * STAGE) + lw * 8 * ROWB;   // piece it * 4 + lw
+                    unsigned char* a = smem + (AB ? ablk_ * A_BYTES : bsp ? buf * A_BYTES : buf * STAGE) + lw * 8 * ROWB;   // piece it * 4 + lw
                     if (r.neg) {   // (wave-uniform)
 #pragma unroll
                         for (int it = 0; it < NA; ++it)
@@ -715,7 +678,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     }
                 }
                 if (part & 2) {
-                    unsigned char* b = smem + (bsh ? BSH_BOFF + buf * bsh_bstride + pb_dst * B1_BYTES : buf * STAGE + B_OFF) + lw * 8 * ROWB;
+                    unsigned char* b = smem + (bsp ? BSP_BOFF + buf * B_BYTES : buf * STAGE + B_OFF) + lw * 8 * ROWB;
 #pragma unroll
                     for (int p = 0; p < PB; ++p) {
                         if (p >= r.npb) break;   // (wave-uniform)
@@ -910,49 +873,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     nb = nb == 2 ? 0 : nb + 1;
                     __builtin_amdgcn_s_barrier();
                 }
-            } else if (bsh2) {
-                // statistics of real-valued data.  Tile j of the slice: A tile into A stage j % 3; the B pieces of a k position --
-                // the positive piece into slot 0, the three negative ones into slots 1-3 of B stage (position & 1) -- are requested
-                // with the position's first tile.  While tile i is multiplied tile i + 2 is requested (its A stage is tile i - 1's;
-                // the B stage was last read by the position before last) and the barrier waits for everything but that request.
-                const int np = g.bsh_np;
-                Walk w = walk_at(t_begin);
-                const int kt0 = w.b;
-                auto issue = [&](int ast) __attribute__((always_inline)) {   // the tile at `w`; returns 1 if the position's B went with it
-                    const Walk c = w;
-                    const TileRef r = walk_ref(c);
-                    walk_next(w);
-                    dma_part(ast, r, 1);
-                    if (c.a != 0) return 0;
-                    const int st = (c.b - kt0) & 1;
-                    dma_part(st, r, 2, 0, 0, 0, 0, 1, 0);                       // (segment 0 is a positive one: its one B piece)
-                    Walk cn = c; cn.a = np;
-                    const TileRef rn = walk_ref(cn);
-                    dma_part(st, rn, 2, 0, 0, 0, 0, 3, 1);                      // the negative pieces
-                    return 1;
-                };
-                issue(0);
-                if (nt > 1) issue(1);
-                if (nt > 1) __builtin_amdgcn_s_waitcnt(vm(NA)); else __builtin_amdgcn_s_waitcnt(VM0);
-                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
-                __builtin_amdgcn_s_barrier();
-                int a2 = 2;
-                for (int i = 0; i < nt; ++i) {
-                    KURBM_LSTAMP(0);
-                    if (i + 2 < nt) {
-                        const int withb = issue(a2);
-                        KURBM_LSTAMP(1);
-                        if (withb) __builtin_amdgcn_s_waitcnt(vm(NA + 4 * NB1)); else __builtin_amdgcn_s_waitcnt(vm(NA));
-                    } else {
-                        KURBM_LSTAMP(1);
-                        __builtin_amdgcn_s_waitcnt(VM0);
-                    }
-                    a2 = (a2 == 2) ? 0 : a2 + 1;
-                    KURBM_LSTAMP(2);
-                    __builtin_amdgcn_s_barrier();
-                    KURBM_LSTAMP(3);
-                }
-                KURBM_LSTAMP_OUT();
             } else if (bsp) {
                 // The paired walk: k position kt = tile T0(kt) [A piece 0 x B pieces 0-2] and tile T1(kt) [A1 x B0-1, A2 x B0].  A tiles
                 // in the order they are consumed, a = 3 kt + piece, live in A stage a & 3; the three B pieces of a position in B
@@ -1009,57 +929,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     sa = (sa + 3) & 3;
                 }
                 KURBM_LSTAMP_OUT();
-            } else if (bsh) {
-                // tile t = 3 kt + p: A piece p of k position kt into A stage t % 3 = p, the position's three B pieces into B stage
-                // kt & 1.  While tile i is multiplied, tile i + 2 is requested -- its A stage is tile i - 1's -- and with it ONE B
-                // piece of the k position at or behind it, so that every request is 10 pieces per wave: with tile (kt, 1) piece 2 of
-                // position kt + 1 (the tiles of kt - 1 that read that piece of the stage are behind their barriers), with tile
-                // (kt, 2) its piece 1, with tile (kt + 1, 0) its piece 0.  The barrier waits for everything but that request:
-                // tile i + 1 has landed.
-                Walk w = walk_at(t_begin);
-                TileRef rb = walk_ref(w);                        // (B of k position 0; its offset moves on by 128 bytes per position)
-                rb.npb = 3;
-                {
-                    const TileRef r0 = rb; walk_next(w);
-                    dma_part(0, r0, 1); dma_part(0, rb, 2);                          // tile 0: A piece 0, all of B(0)
-                    rb.ob += 128u;                                                   // -> position 1, stage 1
-                    if (nt > 1) {
-                        const TileRef r1 = walk_ref(w); walk_next(w);
-                        dma_part(1, r1, 1);                                          // tile 1: A piece 1
-                        if (nt > 3) dma_part(1, rb, 2, 0, 0, 0, 2, 3);               // ... and piece 2 of B(1)
-                    }
-                }
-                if (nt > 3) __builtin_amdgcn_s_waitcnt(vm(NA + NB1)); else if (nt > 1) __builtin_amdgcn_s_waitcnt(vm(NA)); else __builtin_amdgcn_s_waitcnt(VM0);
-                __builtin_amdgcn_s_setprio(KURBM_PRIO_LOADER);   // (the first requests are out)
-                __builtin_amdgcn_s_barrier();
-                int p2 = 2, bst = 1;                             // tile i + 2: its piece (= A stage); the B stage being filled
-                for (int i = 0; i < nt; ++i) {
-                    KURBM_LSTAMP(0);
-                    if (i + 2 < nt) {
-                        const TileRef r = walk_ref(w); walk_next(w);
-                        dma_part(p2, r, 1);
-                        // B piece (3 - p2) % 3 of the position being filled, if there is one: i + 2 + (its distance to that position's first tile) < nt
-                        const int first = i + 2 + ((3 - p2) % 3);
-                        KURBM_LSTAMP(1);
-                        if (first < nt) {
-                            if (p2 == 2) dma_part(bst, rb, 2, 0, 0, 0, 1, 2);
-                            else if (p2 == 0) dma_part(bst, rb, 2, 0, 0, 0, 0, 1);
-                            else dma_part(bst, rb, 2, 0, 0, 0, 2, 3);
-                            __builtin_amdgcn_s_waitcnt(vm(NA + NB1));
-                        } else {
-                            __builtin_amdgcn_s_waitcnt(vm(NA));
-                        }
-                        if (p2 == 0) { rb.ob += 128u; bst ^= 1; }   // (position complete: on to the next one, the other stage)
-                    } else {
-                        KURBM_LSTAMP(1);
-                        __builtin_amdgcn_s_waitcnt(VM0);
-                    }
-                    if (++p2 == 3) p2 = 0;
-                    KURBM_LSTAMP(2);
-                    __builtin_amdgcn_s_barrier();
-                    KURBM_LSTAMP(3);
-                }
-                KURBM_LSTAMP_OUT();
             } else {
             // both stages are free at the start: tiles 0 and 1 are requested back to back, and the first barrier waits for
             // tile 0's pieces only (a counted vmcnt leaves tile 1's in flight)
@@ -1113,16 +982,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         }
         __syncthreads();
         // keep the MFMA waves' epilogue barriers company: one per patch write, one between the pieces of a plane
-        if (EPI == EPI_SLAB && g.fuse) {
-            // fused reduction (below): the patch, the arrival, the poll's verdict, then two per chunk of the own rows
-            __syncthreads();
-            __syncthreads();
-            __syncthreads();
-            if (*reinterpret_cast<volatile unsigned*>(smem + FUSE_FLAG_OFF)) {
-                const FuseRows fr = fuse_rows(g, m0, z);
-                for (int r0 = fr.lo; r0 < fr.hi; r0 += FUSE_RC) { __syncthreads(); __syncthreads(); }
-            }
-        } else if (EPI == EPI_SLAB || EPI == EPI_SOFTPLUS) __syncthreads();
+        if (EPI == EPI_SLAB || EPI == EPI_SOFTPLUS) __syncthreads();
         else {
             if (RP) { __syncthreads(); __syncthreads(); }   // (the row partials' trip through LDS)
             if (g.out) {
@@ -1132,8 +992,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
         }
         return;
     }
-    if (EPI == EPI_HALFSTEP && g.zero_words && blockIdx.x == 0)   // the arrival counters of the statistics launch behind this one
-        for (int i = tid; i < g.n_zero; i += NT) g.zero_words[i] = 0u;   // (the MFMA waves: off the loaders' way to their first requests)
     if constexpr (NI_LDS > 0) {
         if (nt > 0) {
 #pragma unroll
@@ -1147,12 +1005,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     *reinterpret_cast<u32x4*>(smem + SMEM_BYTES + ((ni * TM + mi) * NT + tid) * 16) = u32x4{w[0], w[1], w[2], w[3]};
                 }
         }
-    }
-    if (EPI == EPI_SLAB && g.fuse) {
-        // fused reduction: the bias column sums -- their partials were complete before this launch -- under the flight of the
-        // first tiles, one wave per 8 columns (kurbm_kernels.h)
-        const int nbw = bias_waves(g.red);
-        for (int gi = (int)blockIdx.x * (NT / 64) + wave; gi < nbw; gi += nwg * (NT / 64)) bias_colsum_wave(g.red, gi, lane);
     }
     __builtin_amdgcn_s_setprio(KURBM_PRIO_MFMA);   // the MFMA waves go first wherever a loader wave competes for issue (the reverse: no difference)
     if (nt > 0) {
@@ -1349,21 +1201,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 }
                 if (i < nt) one_tile(0, 0, std::integral_constant<int, PB>{});
             } else {
-                if (bsh2) {
-                    // (see the loaders) run-time stages; a tile's piece count comes from the segment table
-                    const int np = g.bsh_np, ns = g.nseg;
-                    int ast = 0, bst = 0, seg = 0;
-                    for (; i < nt; ++i) {
-                        const int segn = (seg + 1 == ns) ? 0 : seg + 1;
-                        const int astn = (ast == 2) ? 0 : ast + 1, bstn = (segn == 0) ? (bst ^ 1) : bst;
-                        const int pb0 = (seg < np) ? 0 : 1, pb0n = (segn < np) ? 0 : 1;
-                        const int npb = (int)((__builtin_amdgcn_readlane(t_code, seg) >> 2) & 3u);
-                        if (npb == 3) one_tile(ast, 0, std::integral_constant<int, 3>{}, bst, astn, bstn, pb0, pb0n);
-                        else if (npb == 2) one_tile(ast, 0, std::integral_constant<int, 2>{}, bst, astn, bstn, pb0, pb0n);
-                        else one_tile(ast, 0, std::integral_constant<int, 1>{}, bst, astn, bstn, pb0, pb0n);
-                        seg = segn; ast = astn; bst = bstn;
-                    }
-                } else if (bsp) {
+                if (bsp) {
                     // (see the loaders) k position kt: one three-piece tile on A stage (3 kt) & 3, then the paired tile on the next two
                     const int np = nt / 3;
                     int s0 = 0;
@@ -1385,15 +1223,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                         s0 = s3;
                     }
                     i = nt;
-                } else if (bsh) {
-                    // k position kt = tiles (A piece 0 x 3 B pieces), (piece 1 x 2), (piece 2 x 1): A stage = the piece, B stage =
-                    // kt & 1 for all three -- six tiles per trip
-                    typedef std::integral_constant<int, 3> N3; typedef std::integral_constant<int, 2> N2; typedef std::integral_constant<int, 1> N1;
-                    for (; i + 5 < nt; i += 6) {
-                        one_tile(0, 0, N3{}, 0, 1, 0); one_tile(1, 0, N2{}, 0, 2, 0); one_tile(2, 0, N1{}, 0, 0, 1);
-                        one_tile(0, 0, N3{}, 1, 1, 1); one_tile(1, 0, N2{}, 1, 2, 1); one_tile(2, 0, N1{}, 1, 0, 0);
-                    }
-                    if (i < nt) { one_tile(0, 0, N3{}, 0, 1, 0); one_tile(1, 0, N2{}, 0, 2, 0); one_tile(2, 0, N1{}, 0, 0, 1); }
                 } else if (F8 && g.walk3) {
                     // whole units of fp8, 3-piece, 3-piece; the stages alternate: six tiles per trip
                     for (; i + 5 < nt; i += 6) {
@@ -1469,129 +1298,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                         (n0 + wn * WN + ni * 16 + l15 < g.N) ? ((ABS || ABP) ? 0.5f * acc[mi][ni][r] : acc[mi][ni][r]) : 0.f;
         __syncthreads();
         constexpr int CH = BN / 4;   // 16-B chunks per row
-        if (!g.fuse) {
-#pragma unroll
-            for (int j = 0; j < BM * CH / NT; ++j) {
-                const int q = j * NT + tid, row = q / CH, c = q % CH;
-                const int gr = m0 + row, gc = n0 + 4 * c;
-                if (gr < g.M && gc < g.ld_slab) {   // ld_slab = N rounded up to 4: the chunk stays inside the row
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * PROW32 + 16 * c);
-                    *reinterpret_cast<f32x4*>(slab + (size_t)gr * g.ld_slab + gc) = v;
-                }
-            }
-            KURBM_STAMP_OUT();
-            return;
-        }
-        // ---- fused reduction: this launch is also the slab reduction, the weight update and the mirror rewrite -----------
-        // The nsplit k-slices of an output tile run at the same time (the host fuses only when the whole grid is resident,
-        // one workgroup per CU).  Slice z keeps the tile rows it will reduce itself -- its share [lo, hi) of the tile's rows
-        // inside the matrix -- in the LDS patch and stores only the OTHER rows to slab z, write-through (sc1: the readers sit
-        // on other XCDs, whose L2s do not snoop this one); every storing wave drains its stores, the workgroup meets, ONE
-        // lane counts it in on the tile's arrival counter (agent-scope atomic) and polls that word (sc1 loads) until all
-        // slices have arrived.  Then it sums its rows over the slabs IN SLAB ORDER -- its own from LDS, the others by sc1
-        // loads, which bypass this CU's L1 -- exactly the additions of k_reduce_apply_split, so W and the mirror come out
-        // bit-identical to the two-launch sequence; W += lr * sum, the new weights as bf16 pieces row-major and, through an
-        // LDS transpose, transposed.  (cdna_hip_programming.md, Guideline 16: R1 publish, sc1 consume; MI355X_MICROARCH.md,
-        // visibility table row 1.)  A poll that runs into its bound -- only possible when the grid is NOT resident -- sets
-        // bit 0 of the context's status word and leaves W alone: kurbm_ctx_status reports it, nothing hangs.
-        const FuseRows fr = fuse_rows(g, m0, z);
-        typedef __attribute__((address_space(1))) unsigned gu32;
-        const rsrc_t dS = __builtin_amdgcn_make_buffer_rsrc(g.slab, 0, 0xFFFFFFFF, 0x00020000);
 #pragma unroll
         for (int j = 0; j < BM * CH / NT; ++j) {
             const int q = j * NT + tid, row = q / CH, c = q % CH;
             const int gr = m0 + row, gc = n0 + 4 * c;
-            if (gr < g.M && gc < g.ld_slab && (row < fr.lo || row >= fr.hi)) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * PROW32 + 16 * c);
-                __builtin_amdgcn_raw_buffer_store_b128(v, dS, (int)(((size_t)z * g.slab_stride + (size_t)gr * g.ld_slab + gc) * 4), 0, 16);
+            if (gr < g.M && gc < g.ld_slab) {   // ld_slab = N rounded up to 4: the chunk stays inside the row
+                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * PROW32 + 16 * c);
+                *reinterpret_cast<f32x4*>(slab + (size_t)gr * g.ld_slab + gc) = v;
             }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its slab rows have left
-        __syncthreads();
-        if (tid == 0) {
-            unsigned ok = 1u;
-            if (g.nsplit > 1) {
-                gu32* cnt = (gu32*)(g.sync + bm * g.grid_n + bn);
-                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned long long t0, t1;
-                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.nsplit) {
-                    __builtin_amdgcn_s_sleep(4);
-                    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-                    if (t1 - t0 > 20000000ull) {   // 0.2 s of the 100 MHz clock: the grid is not resident
-                        ok = 0u;
-                        __hip_atomic_fetch_or((gu32*)g.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            *reinterpret_cast<volatile unsigned*>(smem + FUSE_FLAG_OFF) = ok;
-        }
-        __syncthreads();
-        if (*reinterpret_cast<volatile unsigned*>(smem + FUSE_FLAG_OFF) == 0u) { KURBM_STAMP_OUT(); return; }
-        const ReduceArgs& a = g.red;
-        float* ctile = reinterpret_cast<float*>(smem + FUSE_TILE_OFF);      // [FUSE_RC][BN + 1]
-        auto store3 = [&](uint16_t* dst, size_t plane, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
-            float v[4] = {v0, v1, v2, v3};
-            for (int j = 0; j < a.pieces; ++j) {
-                u32x2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-                *reinterpret_cast<u32x2*>(dst + j * plane) = pk;
-                if (j + 1 < a.pieces) {
-                    v[0] -= bf16_bits_to_f32(pk.x & 0xFFFFu); v[1] -= bf16_bits_to_f32(pk.x >> 16);
-                    v[2] -= bf16_bits_to_f32(pk.y & 0xFFFFu); v[3] -= bf16_bits_to_f32(pk.y >> 16);
-                }
-            }
-        };
-        for (int r0 = fr.lo; r0 < fr.hi; r0 += FUSE_RC) {
-#pragma unroll
-            for (int j = 0; j < FUSE_RC * CH / NT; ++j) {
-                const int q = j * NT + tid, rl = q / CH, c = q % CH;
-                const int row = r0 + rl, gr = m0 + row, gc = n0 + 4 * c;
-                f32x4 w = {0.f, 0.f, 0.f, 0.f};
-                if (row < fr.hi && gr < g.M && gc < g.N) {
-                    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-                    for (int z0 = 0; z0 < g.nsplit; z0 += 4) {   // four slabs in flight, added in slab order
-                        f32x4 v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int zz = z0 + e;
-                            if (zz >= g.nsplit) continue;
-                            if (zz == z) v[e] = *reinterpret_cast<const f32x4*>(smem + row * PROW32 + 16 * c);
-                            else v[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                     dS, (int)(((size_t)zz * g.slab_stride + (size_t)gr * g.ld_slab + gc) * 4), 0, 16));
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (z0 + e < g.nsplit) sum += v[e];
-                    }
-                    float* wp = a.W + (size_t)gr * a.ldw + gc;                  // ldw % 4 == 0
-                    w = *reinterpret_cast<const f32x4*>(wp);
-                    w = w + sum * a.lr;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (gc + e >= g.N) w[e] = 0.f;                          // the row padding stays zero
-                    *reinterpret_cast<f32x4*>(wp) = w;
-                    if (a.Wb) store3(a.Wb + (size_t)gr * a.ldWb + gc, a.planeWb, w.x, w.y, w.z, w.w);
-                }
-                float* ct = ctile + rl * FUSE_TILE_ROW + 4 * c;
-                ct[0] = w.x; ct[1] = w.y; ct[2] = w.z; ct[3] = w.w;
-            }
-            __syncthreads();
-            if (a.Wtb) {
-                // FUSE_RC / 4 lanes x 4 rows down a column of the chunk: runs of 2 FUSE_RC bytes per column and piece
-                constexpr int LPC = FUSE_RC / 4;
-#pragma unroll
-                for (int j = 0; j < LPC * BN / NT; ++j) {
-                    const int q = j * NT + tid, rr4 = (q % LPC) * 4, cl = q / LPC;
-                    const int cc = n0 + cl, rr = m0 + r0 + rr4;
-                    if (r0 + rr4 < fr.hi && cc < g.N && rr < a.ldWtb)
-                        store3(a.Wtb + (size_t)cc * a.ldWtb + rr, a.planeWtb, ctile[(rr4 + 0) * FUSE_TILE_ROW + cl],
-                               ctile[(rr4 + 1) * FUSE_TILE_ROW + cl], ctile[(rr4 + 2) * FUSE_TILE_ROW + cl],
-                               ctile[(rr4 + 3) * FUSE_TILE_ROW + cl]);
-                }
-            }
-            __syncthreads();
         }
         KURBM_STAMP_OUT();
         return;
@@ -2038,7 +1752,7 @@ static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
                 KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true>), dim3(nblk), dim3(768), 0, st, g);
             } else {
                 // the plain byte-plane walk (ABP): one segment of three pieces, k slices of whole 128-deep blocks, no in-launch reduction
-                if (g.nseg != 1 || (int)((g.seg_codes >> 2) & 3u) != 3 || (g.kt_per_split & 1) || g.fuse || g.f8pos) return hipErrorInvalidValue;
+                if (g.nseg != 1 || (int)((g.seg_codes >> 2) & 3u) != 3 || (g.kt_per_split & 1) || g.f8pos) return hipErrorInvalidValue;
                 KURBM_LAUNCH((k_gemm_pb<256, 64, 4, 2, 64, PBN, E, NZ, true, true>), dim3(nblk), dim3(768), 0, st, g);
             }
             return hipGetLastError();
@@ -2097,29 +1811,15 @@ hipError_t launch_gemm_pb(int epi, const GemmArgsB& g_in, hipStream_t st) {
     }
     // shared B staging: a three-piece A operand against three-piece weights, (piece p) x (pieces 0 .. 2 - p), one k slice
     {
+        // the PAIRED walk (k_gemm_pb, "BSP"): a three-piece A operand against three-piece B rows -- segments (A piece p) x (B pieces
+        // 0 .. 2 - p) of ONE operand set, walked segment-fastest -- on 128 x 128 tiles as two tiles per k position: the half steps on a
+        // real-valued batch, and the statistics GEMM whose only segments are these three (the negative phase of Gaussian visibles),
+        // any number of k slices of whole positions
         const bool tri = g.pb_max == 3 && !g.a_bytes && g.nseg == 3 && g.seg_fastest && ((g.seg_codes >> 4) & 1ull) == ((g.seg_codes >> 9) & 1ull) &&
                          ((g.seg_codes >> 4) & 1ull) == ((g.seg_codes >> 14) & 1ull) &&
                          (g.seg_codes & 0x7FFFull & ~0x4210ull) == ((0ull | (3ull << 2)) | ((1ull | (2ull << 2)) << 5) | ((2ull | (1ull << 2)) << 10));
-        g.bshare = (epi == EPI_HALFSTEP && tri && g.nsplit == 1 && !((g.seg_codes >> 4) & 1ull)) ? 1 : 0;
-        // ... on 128 x 128 tiles the PAIRED walk (k_gemm_pb, "BSP"): two tiles per k position; also the statistics GEMM whose only
-        // segments are these three (the negative phase of Gaussian visibles), any number of k slices of whole positions
-        if (tri && g.pair_ok && g.cfg == 0 && (epi == EPI_HALFSTEP ? g.bshare == 1 : (epi == EPI_SLAB && !g.f8pos && !g.fuse)) &&
-            g.kt_per_split % 3 == 0 && g.kt_total % 3 == 0)
-            g.bshare = 2;
-    }
-    // the statistics of real-valued data: positive segments (set 0, one B piece each) in front of the negative ones (set 1, the
-    // first with three B pieces), segment-fastest, whole k positions per slice, no fp8 tiles
-    g.bshare2 = 0; g.bsh_np = 0;
-    if (epi == EPI_SLAB && g.pb_max == 3 && !g.a_bytes && !g.f8pos && g.seg_fastest && g.cfg == 2 && g.nseg >= 2 && g.nseg <= 12 &&
-        g.kt_per_split % g.nseg == 0 && g.kt_total % g.nseg == 0 && g.bshare_ok) {
-        int np = 0, ok = 1;
-        for (int sg = 0; sg < g.nseg; ++sg) {
-            const unsigned code = (unsigned)(g.seg_codes >> (5 * sg)) & 31u;
-            const int neg = (code >> 4) & 1, npb = (code >> 2) & 3;
-            if (!neg) { if (np != sg || npb != 1) ok = 0; else ++np; }            // positive ones first, one piece each
-            else if (sg == np && npb != 3) ok = 0;                                // the first negative one brings all three pieces
-        }
-        if (ok && np >= 1 && np < g.nseg) { g.bshare2 = 1; g.bsh_np = np; }
+        g.bshare = (tri && g.pair_ok && g.cfg == 0 && (epi == EPI_HALFSTEP ? (g.nsplit == 1 && !((g.seg_codes >> 4) & 1ull)) : (epi == EPI_SLAB && !g.f8pos)) &&
+                    g.kt_per_split % 3 == 0 && g.kt_total % 3 == 0) ? 2 : 0;
     }
     if (g.a_tr && !(g.bshare == 2 && epi == EPI_SLAB)) return hipErrorInvalidValue;   // (only that walk reads a row-major A operand)
     g.walk3 = (epi == EPI_SLAB && g.pb_max == 3 && g.f8pos && g.nseg == 2 && ((g.seg_codes >> 7) & 3u) == 3u &&

@@ -219,14 +219,16 @@ class DeviceRBM:
         return 1 if v.bf16_exact else 3
 
     def check_status(self):
-        """Raise if a kernel of this context reported a problem (kurbm_ctx_status; synchronises with the device).  The only
-        bit there is: a statistics launch that reduces its own slabs (KURBM_X3_FUSED=1, off by default) gave up waiting for
-        the other k-slices of its tile and left W and its mirror partly updated -- training must not go on from that state."""
+        """Raise if a kernel of this context reported a problem (kurbm_ctx_status; synchronises with the device).  Both bits there
+        are mean a device-side wait ran into its bound and an update was SKIPPED -- training must not go on from that state: bit 1 =
+        the peer exchange (a rank never arrived), bit 2 = the grid barrier of the one-launch small step (its grid was not resident:
+        a CU mask, a device shared with another process)."""
         bits = self.ctx.status()
         if bits:
-            raise _lib.KurbmError("kurbm status %#x: a statistics launch that reduces its own slabs (KURBM_X3_FUSED=1) found its "
-                                  "grid not resident (CU mask / shared device) and skipped an update of W; the weights and their "
-                                  "bf16 mirror are inconsistent -- reload them (set_weights) and train with KURBM_X3_FUSED=0" % bits)
+            what = [name for bit, name in ((2, "the peer exchange timed out waiting for a rank"),
+                                           (4, "the one-launch small step found its grid not resident")) if bits & bit]
+            raise _lib.KurbmError("kurbm status %#x: %s; an update was skipped and the replicas / weights are no longer what the "
+                                  "step sequence defines -- reload the weights (set_weights)" % (bits, "; ".join(what) or "unknown bit"))
 
     def get_weights(self):
         out = self.W.to_numpy(), self.b_h.cpu().numpy(), self.b_v.cpu().numpy()     # (device -> host copies: a sync)

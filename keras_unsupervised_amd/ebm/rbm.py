@@ -339,8 +339,6 @@ class RBM(object):
             self.last_scores.append(score)
             print("\n{0:d}/{1:d}, score: {2:f}".format(label[0], label[1], score))   # rbm.py:234
         ring = _ScoreRing(d.device, print_score) if verbose == 1 else None
-        import os
-        fused_knob = os.environ.get("KURBM_X3_FUSED", "0") not in ("", "0")
         for epoch in range(int(self.hps["epochs"])):                              # rbm.py:113
             if verbose == 1:
                 print(epoch + 1, "/", self.hps["epochs"], " epochs", end="\r")   # rbm.py:115
@@ -363,10 +361,8 @@ class RBM(object):
                     ring.push(self._score(Vd, lo, rows, step), (i + 1, num_step))
             if ring is not None:
                 ring.flush()                                                     # an epoch's lines end with the epoch
-            if fused_knob:
-                d.check_status()          # (a synchronisation per epoch, only where the in-launch slab reduction was asked for)
         self._planes = None
-        d.check_status()                  # fit() ends with one status read: no further step runs on a half-applied update
+        d.check_status()                  # fit() ends with one status read: no later call trains on from a skipped update
         return None
 
     def _compute(self):

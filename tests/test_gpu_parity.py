@@ -1351,55 +1351,10 @@ def test_x3_fp8_positive_statistics(gpu_device, ctx_option, cfg):
             np.mean(np.abs(got[1][0] - dW) > 1e-3) < 0.05   # (a band flip moves one row / column of dW by one count)
 
 
-@pytest.mark.parametrize("cfg", [dict(B=4096, nv=784, nh=1024), dict(B=4096, nv=784, nh=1024, planes=True, steps=3),
-                                 dict(B=1024, nv=784, nh=256), dict(B=512, nv=300, nh=200), dict(B=256, nv=130, nh=70),
-                                 dict(B=2048, nv=1024, nh=784, real=True), dict(B=1024, nv=784, nh=512, gauss=True),
-                                 dict(B=1024, nv=1024, nh=1024, compute="bf16"), dict(B=640, nv=784, nh=1024, k=2, persistent=True),
-                                 dict(B=4096, nv=784, nh=1024, split=3), dict(B=4096, nv=784, nh=1024, split=1),
-                                 dict(B=4096, nv=784, nh=1024, stats_tall=0)])
-def test_fused_slab_reduction_is_bit_identical(gpu_device, ctx_option, cfg):
-    """The statistics GEMM that reduces its own split-K slabs (KURBM_X3_FUSED=1, wherever its grid is resident; off by default:
-    no faster) against the two-launch sequence (statistics, then k_reduce_apply_split): the same additions in the same order, so W,
-    b_h, b_v AND the weight-piece mirror (both orientations, k padding included) come out bit for bit the same -- from a
-    0xFF-filled workspace too (the arrival counters are zeroed by the half step in front, not by the caller) -- and the
-    context's status word stays clear.  rbm.py:125-134."""
-    from keras_unsupervised_amd._lib import Context
-    B, nv, nh = cfg["B"], cfg["nv"], cfg["nh"]
-    compute, steps = cfg.get("compute", "x3"), cfg.get("steps", 2)
-    mode = O.MODE_VISIBLE_GAUSSIAN if cfg.get("gauss") else O.MODE_VISIBLE_BERNOULLI
-    if "split" in cfg:
-        ctx_option("KURBM_BF16_SPLIT", cfg["split"], -1)
-    if "stats_tall" in cfg:
-        ctx_option("KURBM_X3_STATS_TALL", cfg["stats_tall"], 1)
-    W0 = synthetic_params(nv, nh, seed=2100 + B)
-    V = synthetic_real(B, nv, seed=2101 + B) if (cfg.get("real") or cfg.get("gauss")) else synthetic_binary(B, nv, seed=2101 + B, p=0.3)
-    got = {}
-    for fused in (1, 0):
-        ctx_option("KURBM_X3_FUSED", fused, 0)
-        e = _engine(*W0, gpu_device)
-        vd = _dm(V, gpu_device)
-        pieces = 1 if compute == "bf16" else 3
-        vp = 1 if compute == "bf16" else e.v_pieces(vd)
-        e.workspace_bf16(B, cfg.get("k", 1), pieces, vp if compute == "bf16" else e._x3_pieces(vd, None, mode)).fill_(0xFF if fused else 0)
-        chain = None
-        if cfg.get("persistent"):
-            from keras_unsupervised_amd.ebm.engine import DeviceMatrix
-            chain = DeviceMatrix.from_host(synthetic_binary(B, nv, seed=2102 + B, p=0.5), gpu_device)
-        planes = e.make_planes(vd, [(0, B)], mode, chain) if cfg.get("planes") else None
-        for step in range(steps):
-            e.cd_step(vd, B, 0, 1e-3, 9, step, k=cfg.get("k", 1), mode=mode, compute=compute, planes=planes, v_chain=chain)
-        torch.cuda.synchronize()
-        got[fused] = [x.copy() for x in e.get_weights()] + [e._mirrors[pieces][0].cpu().numpy().copy()]
-        assert Context.get(gpu_device.index).status() == 0
-    for a, b in zip(got[1], got[0]):
-        assert np.array_equal(a, b)
-    assert np.all(np.isfinite(got[1][0])) and not np.array_equal(got[1][0], W0[0])
-
-
 @pytest.mark.parametrize("shape", [(4096, 784, 1024), (1024, 1000, 300), (512, 260, 1024), (300, 784, 100)])
-def test_shared_b_half_step_equals_segment_by_segment(gpu_device, ctx_option, shape):
-    """A real-valued A operand on the x3 path: the three tiles of a k position sharing one staging of its B pieces
-    (KURBM_X3_BSHARE=1, the default: segments walked k position by k position) against the segments one after the other
+def test_paired_walk_half_step_equals_segment_by_segment(gpu_device, ctx_option, shape):
+    """A real-valued A operand on the x3 path: the paired walk (KURBM_X3_PAIR=1, the default: two tiles per k position on 128 x 128
+    tiles, the six piece pairs of a position together) against the three segments one after the other on the generic walk
     (=0).  The same piece pairs, multiplied exactly, summed in another order: the probabilities agree to fp32 rounding, the
     uniforms are the same numbers, and both sit within the fp32 tolerance of the oracle.  rbm.py:214."""
     B, nv, nh = shape
@@ -1407,7 +1362,7 @@ def test_shared_b_half_step_equals_segment_by_segment(gpu_device, ctx_option, sh
     V = synthetic_real(B, nv, seed=2501 + B)
     got = {}
     for share in (1, 0):
-        ctx_option("KURBM_X3_BSHARE", share, 1)
+        ctx_option("KURBM_X3_PAIR", share, 1)
         e = _engine(*W0, gpu_device)
         out = e.half_step_bf16("vh", _dm(V, gpu_device), B, 0, 1, 5, 2, 3, pieces=3)
         torch.cuda.synchronize()

@@ -29,9 +29,9 @@ def _free_port():
     return port
 
 
-def _run_world2(case, tmp_path, chunks):
-    stem = str(tmp_path / ("%s_c%d" % (case, chunks)))
-    env = dict(os.environ, KURBM_DP_CHUNKS=str(chunks), HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run_world2(case, tmp_path, chunks, exchange="rccl"):
+    stem = str(tmp_path / ("%s_c%d_%s" % (case, chunks, exchange)))
+    env = dict(os.environ, KURBM_DP_CHUNKS=str(chunks), KURBM_DP_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "two_gpu_worker.py"), case, stem]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -40,12 +40,14 @@ def _run_world2(case, tmp_path, chunks):
 
 
 @needs_two
-@pytest.mark.parametrize("chunks", [0, 2])
+@pytest.mark.parametrize("chunks,exchange", [(0, "rccl"), (2, "rccl"), (0, "peer")])
 @pytest.mark.parametrize("case", ["cd1", "pcd2", "gauss", "idle_rank", "bf16", "fp32"])
-def test_fit_world2_equals_one_gpu(gpu_device, tmp_path, case, chunks):
+def test_fit_world2_equals_one_gpu(gpu_device, tmp_path, case, chunks, exchange):
+    """(exchange "peer": the two-shot exchange over hipIpc peer pointers -- between two GPUs the IPC mapping enables peer access;
+    on one shared GPU the same protocol runs in tests/test_peer_exchange.py)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import two_gpu_worker as w
-    ranks = _run_world2(case, tmp_path, chunks)
+    ranks = _run_world2(case, tmp_path, chunks, exchange)
     for key in ("W", "b_h", "b_v", "chain"):
         assert np.array_equal(ranks[0][key], ranks[1][key]), "replicas must stay bit-identical (%s)" % key
     one = w.fit(case, "cuda:0")
