@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_DP_CHUNKS, KN_ANYORDER, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_PAIR, KN_X3_SPLIT_STATS, KN_X3_ATR,
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_DP_CHUNKS, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_PAIR, KN_X3_SPLIT_STATS, KN_X3_ATR,
        KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
@@ -37,8 +37,6 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_X3_XCD2D", 1},         // 0: linear block order of k_gemm_pb instead of one 2-D block of tiles per XCD
     {"KURBM_REDUCE_TR", 0},        // tile height (16 / 32 / 64) of the slab-reduce + mirror launch; 0: by the grid it makes
     {"KURBM_DP_CHUNKS", 0},        // row ranges of dW in the data-parallel step when the caller passes n_chunks <= 0; 0: by message size
-    {"KURBM_ANYORDER", 0},         // TIMING ONLY (results race): bit 0 the half steps, bit 1 the statistics GEMM are launched without
-                                   // the AQL barrier bit -- the upper bound of what overlapping dependent launches could gain
     {"KURBM_X3_STATS_BYTES", 1},   // 0: v_neg^T reaches the statistics GEMM as a bf16 plane (1: as bytes where the positive half is fp8)
     {"KURBM_MAP_SLOW", 0},         // 1: k_gemm_pb maps its blocks by integer division (the path of grids too large for the multiply-high
                                    //    constants: tests)
@@ -907,7 +905,6 @@ static int half_step_b(kurbm_ctx* ctx, int layout, const kurbm_params* p, const 
         g.m_fastest = ctx->knob[KN_X3_MFAST];
         if (o.grid_m_out) *o.grid_m_out = ceil_div(rows, 128);   // (in 128-row units whatever the tile)
         g.xcd2d = ctx->knob[KN_X3_XCD2D]; g.map_force = ctx->knob[KN_MAP_SLOW];
-        g.any_order = ctx->knob[KN_ANYORDER] & 1;
         HIP_TRY(launch_gemm_pb(EPI_HALFSTEP, g, st));
         return KURBM_OK;
     }
@@ -1179,7 +1176,6 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             g.nkt = q.nkt; g.inv_nkt = inv_of(g.nkt);
             g.kt_total = q.kt_total; g.kt_per_split = q.kt_per_split; g.nsplit = q.nsplit;
             g.xcd2d = ctx->knob[KN_X3_XCD2D]; g.map_force = ctx->knob[KN_MAP_SLOW];
-            g.any_order = (ctx->knob[KN_ANYORDER] >> 1) & 1;
             HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
         }
         // ---- positive half, transposed: h_pos^T (bytes) x the pieces of v_pos^T -> slabs [neg.nsplit, +pos.nsplit)
@@ -1198,7 +1194,6 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
             g.nkt = q.nkt; g.inv_nkt = inv_of(g.nkt);
             g.kt_total = q.kt_total; g.kt_per_split = q.kt_per_split; g.nsplit = q.nsplit;
             g.xcd2d = ctx->knob[KN_X3_XCD2D]; g.map_force = ctx->knob[KN_MAP_SLOW];
-            g.any_order = (ctx->knob[KN_ANYORDER] >> 1) & 1;
             HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
         }
     } else if (need_w && KURBM_STAGE(4)) {
@@ -1222,7 +1217,6 @@ static int cd_step_any(kurbm_ctx* ctx, int pieces, int v_pieces, const kurbm_par
         g.nkt = pl.nkt; g.inv_nkt = inv_of(g.nkt);
         g.kt_total = pl.kt_total; g.kt_per_split = pl.kt_per_split; g.nsplit = pl.nsplit;
         g.xcd2d = ctx->knob[KN_X3_XCD2D]; g.map_force = ctx->knob[KN_MAP_SLOW];
-        g.any_order = (ctx->knob[KN_ANYORDER] >> 1) & 1;
         HIP_TRY(launch_gemm_pb(EPI_SLAB, g, st));
     }
     if (mirror_in_reduce) {

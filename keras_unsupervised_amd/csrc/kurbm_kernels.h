@@ -291,7 +291,6 @@ struct GemmArgsB {
                           // tiles are staged as [k][m] and read by transposed LDS reads (k_gemm_pb, "ATR")
     int pair_ok;          // caller: a real-valued A operand on 128 x 128 tiles may walk two tiles per k position (ctx knob KURBM_X3_PAIR; bshare = 2)
     int map_force;        // caller: 1 = map blocks by division whatever the grid (ctx knob KURBM_MAP_SLOW: tests of that path)
-    int any_order;        // caller: TIMING ONLY -- launch without the AQL barrier bit (ctx knob KURBM_ANYORDER); results race
     int xcd2d;            // caller: 1 = let the launcher pick such blocks (ctx knob KURBM_X3_XCD2D), 0 = the linear order
     // softplus epilogue (k_gemm_pb, free energy): rowpart[bn][row] = sum over the tile's columns of softplus(x + bias)
     float* rowpart;

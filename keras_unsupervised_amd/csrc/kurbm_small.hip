@@ -75,6 +75,12 @@ __device__ bool grid_barrier(const SmallArgs& a, unsigned& gen) {
 // plane accessors: agent scope (see grid_barrier)
 __device__ __forceinline__ float ld_plane(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_plane(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... 16 bytes at once: a buffer load with the sc1 bit (agent scope), `base` wave-uniform
+typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld_plane4(const float* base, unsigned byte_off) {
+    const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xFFFFFFFF, 0x00020000);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d, (int)byte_off, 0, 16));
+}
 
 // One 16 x 16 tile of C = A . B over the k chunks [c0, c1) of 16 (stride cs): the lane (x = lane & 15, slot = lane >> 4) feeds
 // k = 16 c + 4 slot + e to MFMA e of a chunk -- A and B agree on that map, so any operand layout works:
@@ -87,9 +93,9 @@ template <bool A_KC, bool B_KC, bool NEG, bool A_PL = false, bool B_PL = false>
 __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A, int lda, bool a_ok, const float* __restrict__ B, int ldb, bool b_ok,
                                          int K, int c0, int c1, int cs, int x, int slot) {
     // UN chunks at a time: ALL their loads are issued before the first MFMA -- the operands come from L2 with a few waves per CU, so
-    // a chunk-by-chunk loop would pay one L2 round trip per chunk.  (Built and measured, round 4, and NOT kept: 16 chunks per batch
-    // with every load unconditional on clamped indices and a select behind it, one tile per wave for h -> v -- every phase took
-    // 10-14 us whatever the batch, 60 against 47 us per step.)
+    // a chunk-by-chunk loop would pay one L2 round trip per chunk.  (Built and measured TWICE, round 4, and NOT kept: every load
+    // unconditional on clamped indices with a select behind it -- 222 branches instead of 641, but hipcc then waits for the loads one
+    // by one (200 s_waitcnt vmcnt instead of 46): phase 1 took 20.5 instead of 5.6 us.  The guarded form keeps its loads in flight.)
     constexpr int UN = 8;
     for (int cb = c0; cb < c1; cb += UN * cs) {
         float av[UN][4], bv[UN][4];
@@ -99,7 +105,10 @@ __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A
             const int k = 16 * c + 4 * slot;
             const bool live = c < c1;
             if (A_KC) {
-                if (!A_PL && live && a_ok && k + 3 < K) { const f32x4 t = *reinterpret_cast<const f32x4*>(A + (size_t)x * lda + k); av[u][0] = t.x; av[u][1] = t.y; av[u][2] = t.z; av[u][3] = t.w; }
+                if (live && a_ok && k + 3 < K) {
+                    const f32x4 t = A_PL ? ld_plane4(A, 4u * (unsigned)(x * lda + k)) : *reinterpret_cast<const f32x4*>(A + (size_t)x * lda + k);
+                    av[u][0] = t.x; av[u][1] = t.y; av[u][2] = t.z; av[u][3] = t.w;
+                }
                 else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) av[u][e] = (live && a_ok && k + e < K) ? (A_PL ? ld_plane(A + (size_t)x * lda + k + e) : A[(size_t)x * lda + k + e]) : 0.f;
@@ -213,6 +222,7 @@ __global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
             const int i = ti * 16 + x, j = tj * 16 + x;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             // dW = v_pos^T . h_pos - v_neg^T . h_neg   (rbm.py:125-126), k = the batch rows: both operands k-strided
+            // (one batch of loads per phase.  Both phases' 128 guarded loads in ONE batch: 15.0 against 8.3 us for this phase -- measured)
             tile_mma<false, false, false, false, true>(acc, a.v + ti * 16, a.ldv, i < a.n_vis, a.h_pos + tj * 16, a.ldh, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
             tile_mma<false, false, true, true, true>(acc, a.v_neg + ti * 16, a.ldn, i < a.n_vis, a.h_neg + tj * 16, a.ldh, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
             const int col = tj * 16 + x, row0 = ti * 16 + 4 * slot;

@@ -651,15 +651,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
             // part: bit 0 = the A tile (AB: pieces [a_lo, a_hi) of A block `ablk_`, whose k offset is r.oa), bit 1 = the B pieces
             auto dma_part = [&](int buf, const TileRef& r, int part, int ablk_ = 0, int a_lo = 0, int a_hi = 1 << 20, int pb_lo = 0,
                                 int pb_hi = PB) __attribute__((always_inline)) {
-#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 1)
-                return;   // timing-only build: no global loads
-#endif
-#if defined(KURBM_ABLATE) && (KURBM_ABLATE & 8)
-                // timing-only build: the tiles of the SECOND and THIRD piece of a real-valued A operand keep the A tile that is
-                // in LDS (garbage results) -- 44 % fewer staged bytes per k position at the same tile and MFMA count: does the
-                // loop follow the bytes or the number of tiles?  
-                if (!AB && (r.oa_piece != 0u)) part &= ~1;
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass drops a kernel's launch stub over the LDS address-space cast)
                 typedef __attribute__((address_space(3))) void* lds_ptr;
                 const int lw = wave - NT / 64;
@@ -1709,15 +1700,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 // ------------------------------------------------------------------------------------
 // one (pieces, epilogue, noise) combination: tile configuration by g.cfg (0: 128 x 128; 2: 256 x 64, half steps only); only
 // the combinations the host plans are instantiated
-// g.any_order (experiment knob KURBM_ANYORDER, TIMING ONLY): the dispatch leaves the AQL barrier bit clear (hipExtAnyOrderLaunch),
-// so its workgroups start as CUs come free under the tail of the launch in front -- without any dependency tracking, i.e. the
-// results race.  It bounds from above what a dependency-tracking version of the same overlap (row-block flags between the half
-// steps of a chain) could gain: DESIGN.md section 4.
-#define KURBM_LAUNCH(kern, grid, block, shmem, st, g)                                                                   \
-    do {                                                                                                               \
-        if ((g).any_order) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, nullptr, nullptr, hipExtAnyOrderLaunch, g); \
-        else hipLaunchKernelGGL(kern, grid, block, shmem, st, g);                                                      \
-    } while (0)
+#define KURBM_LAUNCH(kern, grid, block, shmem, st, g) hipLaunchKernelGGL(kern, grid, block, shmem, st, g)
 template <int PBN, int E, int NZ>
 static hipError_t launch_pb(const GemmArgsB& g, int nblk, hipStream_t st) {
     // byte A planes: ONE segment of PBN pieces, one k slice -- those kernels' loops do not walk a tile list
