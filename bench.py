@@ -111,8 +111,93 @@ def event_time_ms(fn, iters, warm=3):
     return t0.elapsed_time(t1) / iters
 
 
+def choose_exchange(eng, V, device, rank, world, planes, lr, seed, compute):
+    """The exchange of the data-parallel step: KURBM_DP_EXCHANGE = rccl (ncclAllReduce inside libkurbm.so), peer
+    (the two-shot exchange over hipIpc peer pointers) or, the default here, auto: RCCL is created first and is what runs unless the
+    peer exchange (a) comes up on every rank, (b) reproduces RCCL's sum of a test vector and reports no timeout, and (c) runs the
+    data-parallel step faster, by the max over ranks of a short timed probe (every rank takes the same decision: the verdict is
+    all-reduced over the control plane).  Returns (exchange, a note for the JSON line)."""
+    import torch.distributed as dist
+    from keras_unsupervised_amd import _lib
+    from keras_unsupervised_amd.ebm import dp
+    kind = os.environ.get("KURBM_DP_EXCHANGE", "auto").lower()
+    if kind == "peer":
+        return dp.PeerExchange(device, rank, world, N_VIS, N_HID), "peer (KURBM_DP_EXCHANGE=peer)"
+    if kind == "rccl" or compute != "x3":
+        return dp.get_comm(device), "rccl"
+
+    def agree(flag):      # True only if every rank says so
+        if world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def slowest(x):       # max over ranks
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    rccl, rccl_err = None, None
+    try:
+        rccl = dp.get_comm(device)
+    except Exception as e:  # noqa: BLE001  (e.g. BENCH_SHARE_GPU=1: RCCL refuses two ranks on one device)
+        rccl_err = str(e)[:160]
+    if not agree(rccl is not None):
+        if rccl is not None:
+            dp.destroy_comms()
+        sys.stderr.write("bench.py: RCCL communicator unavailable (%s): trying the peer exchange\n" % rccl_err)
+        return dp.PeerExchange(device, rank, world, N_VIS, N_HID), "peer (auto: no RCCL communicator: %s)" % rccl_err
+    px, why = None, None
+    try:
+        os.environ.setdefault("KURBM_PEER_TIMEOUT_MS", "2000")      # (a broken peer path must cost the probe seconds, not minutes)
+        px = dp.PeerExchange(device, rank, world, N_VIS, N_HID)
+    except Exception as e:  # noqa: BLE001  (on EVERY rank or on none: PeerExchange agrees on that itself)
+        why = "peer exchange unavailable (%s)" % str(e)[:120]
+    if px is not None:
+        g = torch.Generator(device="cpu").manual_seed(77 + rank)
+        t0 = torch.randn(N_VIS * N_HID + N_HID + N_VIS, generator=g).to(device)
+        a, b = t0.clone(), t0.clone()
+        rccl.allreduce_sum_(a)
+        px.allreduce_sum_(b)
+        torch.cuda.synchronize()
+        same = bool(torch.allclose(a, b, rtol=1e-5, atol=1e-5)) and eng.ctx.status() == 0
+        if not agree(same):
+            why = "peer exchange failed its self-test against RCCL's sum"
+    if px is not None and why is None:
+        W0 = eng.get_weights()
+        times = {}
+        for name, x in (("rccl", rccl), ("peer", px)):
+            for i in range(5):
+                eng.cd_step_dp(x, V, BATCH, 0, lr, seed, i, row0=rank * BATCH, compute="x3", planes=planes)
+            x.barrier()
+            t = time.perf_counter()
+            for i in range(20):
+                eng.cd_step_dp(x, V, BATCH, 0, lr, seed, 5 + i, row0=rank * BATCH, compute="x3", planes=planes)
+            x.barrier()
+            times[name] = slowest((time.perf_counter() - t) / 20)
+        ok = agree(eng.ctx.status() == 0)
+        eng.set_weights(*W0)
+        if not ok:
+            why = "peer exchange timed out in the probe"
+        elif times["peer"] < times["rccl"]:
+            return px, "peer (auto: probe %.1f us per step against %.1f with RCCL's all-reduce)" % (times["peer"] * 1e6, times["rccl"] * 1e6)
+        else:
+            why = "rccl (auto: probe %.1f us per step against %.1f with the peer exchange)" % (times["rccl"] * 1e6, times["peer"] * 1e6)
+    if px is not None:
+        px.destroy()
+    return rccl, why if why and why.startswith("rccl") else "rccl (auto: %s)" % why
+
+
 def main():
     args = parse_args()
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner on file descriptor 1 when a communicator comes up,
+    # gloo its connection notes -- everything written before the result goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -122,8 +207,10 @@ def main():
         sys.exit("WORLD_SIZE is %d but --gpus is %d: start bench.py without a launcher (it starts its own ranks), or with "
                  "python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py "
                  "--gpus %d ..." % (world, args.gpus, args.gpus, args.gpus))
-    if local_rank >= torch.cuda.device_count():
+    if local_rank >= torch.cuda.device_count() and os.environ.get("BENCH_SHARE_GPU", "0") != "1":
         sys.exit("rank %d: local rank %d has no GPU (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
+    if os.environ.get("BENCH_SHARE_GPU", "0") == "1":
+        local_rank = 0       # rehearsal of the N > 1 path on a one-GPU box: every rank on device 0 (RCCL refuses that; the peer exchange does not)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -148,11 +235,10 @@ def main():
 
     # BENCH_FORCE_DP=1 runs the data-parallel step (1-rank RCCL communicator) on a single-GPU box: a rehearsal of the N > 1 path
     use_dp = world > 1 or os.environ.get("BENCH_FORCE_DP", "0") == "1"
-    # (KURBM_DP_EXCHANGE=peer: the two-shot exchange over hipIpc peer pointers, kurbm_peer_*, instead of RCCL's all-reduce)
-    comm = dp.get_exchange(device, N_VIS, N_HID) if use_dp else None
+    comm, exchange_note = (choose_exchange(eng, V, device, rank, world, planes, lr, seed, args.compute) if use_dp else (None, None))
     rccl_ranks = comm.count() if comm is not None else None
     if comm is not None:
-        assert rccl_ranks == world, "RCCL reports %d ranks, launched %d" % (rccl_ranks, world)
+        assert rccl_ranks == world, "the exchange reports %d ranks, launched %d" % (rccl_ranks, world)
 
     def step(i):
         lo = (i % n_batches) * BATCH
@@ -192,6 +278,7 @@ def main():
         counter[0] += 1
     steady = [timed_block(args.steps) for _ in range(repeats)]
     assert bool(torch.isfinite(eng.W.t).all().item()), "weights diverged"
+    eng.check_status()   # (a device-side wait that timed out -- the peer exchange -- would have skipped updates: not a measurement)
     fence()          # every rank is past its last data-parallel step; from here on only rank 0 touches its GPU
 
     # ---- the honest variants, under the SAME block protocol as `value` (single GPU, x3) -------------------------------------
@@ -387,9 +474,10 @@ def main():
                        "data_planes": None if planes is None else "resident: bf16 planes of the 16 batch windows made once before the warm-up "
                                       "(%.0f MB), as RBM.fit does once per call; paths.x3_convert_per_step converts the batch in every step" % (planes.buf.numel() / 1e6),
                        "data_parallel_step": None if comm is None else (
-                           "kurbm_cd_step_x3_peer (two-shot all-reduce over hipIpc peer pointers, the apply fused into its second shot: KURBM_DP_EXCHANGE=peer)"
-                           if dp.exchange_kind() == "peer" else
+                           "kurbm_cd_step_x3_peer (two-shot all-reduce over hipIpc peer pointers, the apply fused into its second shot)"
+                           if hasattr(comm, "capacity") else
                            "kurbm_cd_step_x3_dp (RCCL all-reduce inside libkurbm.so; row ranges: KURBM_DP_CHUNKS, default one)"),
+                       "exchange": exchange_note,
                        "timing": {"blocks": repeats, "steps_per_block": args.steps,
                                   "value": "N x K / median block time; W = %d untimed warm-up steps before the first block" % args.warmup,
                                   "value_first_block": "first block alone (cold clocks)",
@@ -404,11 +492,16 @@ def main():
     if dist.is_initialized():
         dist.barrier()   # (gloo: the other ranks wait here, on the host, while rank 0 measures)
     if comm is not None:
+        if hasattr(comm, "capacity"):
+            comm.destroy()
         dp.destroy_comms()
     if dist.is_initialized():
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
     if out is not None:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -159,8 +159,8 @@ class Context:
         self.lib = lib
 
     def status(self):
-        """Sticky status bits of the context's kernels, read back and cleared (synchronises with the device): bit 0 = a
-        fused statistics launch found its grid not resident and left W alone (include/kurbm.h: kurbm_ctx_status)."""
+        """Sticky status bits of the context's kernels, read back and cleared (synchronises with the device): a device-side wait
+        ran into its bound and skipped its work -- bit 1 the peer exchange, bit 2 the small step's grid barrier (include/kurbm.h)."""
         bits = _i(0)
         check(self.lib.kurbm_ctx_status(self.handle, C.byref(bits)))
         return int(bits.value)

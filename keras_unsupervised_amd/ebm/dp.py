@@ -113,8 +113,19 @@ class PeerExchange:
             handles = [None] * self.world_size
             dist.all_gather_object(handles, bytes(buf.raw))
             blob = b"".join(handles)
-            _lib.check(self.lib.kurbm_peer_connect(self.handle, C.create_string_buffer(blob, len(blob)), len(blob)))
-            dist.barrier()        # nobody starts a step before every rank has mapped every buffer
+            err = None
+            try:
+                _lib.check(self.lib.kurbm_peer_connect(self.handle, C.create_string_buffer(blob, len(blob)), len(blob)))
+            except _lib.KurbmError as e:      # (e.g. no peer access between two devices)
+                err = e
+            # every rank learns whether EVERY rank has mapped every buffer (this is also the barrier in front of the first step):
+            # a rank that failed must not leave the others waiting for it inside a step
+            oks = [None] * self.world_size
+            dist.all_gather_object(oks, err is None)
+            if not all(oks):
+                self.destroy()
+                raise _lib.KurbmError("peer exchange: ranks %s could not map the other ranks' buffers%s"
+                                      % ([r for r, ok in enumerate(oks) if not ok], "" if err is None else " (this rank: %s)" % err))
         self.capacity = self.n_vis * self.n_hid + self.n_hid + self.n_vis
 
     def count(self):
