@@ -157,15 +157,20 @@ def choose_exchange(eng, V, device, rank, world, planes, lr, seed, compute):
     except Exception as e:  # noqa: BLE001  (on EVERY rank or on none: PeerExchange agrees on that itself)
         why = "peer exchange unavailable (%s)" % str(e)[:120]
     if px is not None:
+        # several exchanges of DIFFERENT vectors through the same buffers (a stale read of a peer's buffer -- a cached line of the
+        # epoch before -- would show from the second one on), each against RCCL's sum of the same vectors
         g = torch.Generator(device="cpu").manual_seed(77 + rank)
-        t0 = torch.randn(N_VIS * N_HID + N_HID + N_VIS, generator=g).to(device)
-        a, b = t0.clone(), t0.clone()
-        rccl.allreduce_sum_(a)
-        px.allreduce_sum_(b)
-        torch.cuda.synchronize()
-        same = bool(torch.allclose(a, b, rtol=1e-5, atol=1e-5)) and eng.ctx.status() == 0
+        same = True
+        for _ in range(4):
+            t0 = torch.randn(N_VIS * N_HID + N_HID + N_VIS, generator=g).to(device)
+            a, b = t0.clone(), t0.clone()
+            rccl.allreduce_sum_(a)
+            px.allreduce_sum_(b)
+            torch.cuda.synchronize()
+            same = same and bool(torch.allclose(a, b, rtol=1e-5, atol=1e-5))
+        same = same and eng.ctx.status() == 0
         if not agree(same):
-            why = "peer exchange failed its self-test against RCCL's sum"
+            why = "peer exchange failed its self-test against RCCL's sums"
     if px is not None and why is None:
         W0 = eng.get_weights()
         times = {}
