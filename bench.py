@@ -12,7 +12,8 @@ bf16 triples on the bf16 matrix cores -- held to the fp32 oracle and the fp32 to
 and Gaussian-mode (the reference's default) variants.
 
 Timing protocol: W untimed warm-up steps, then R blocks of exactly K steps, each bracketed by a barrier +
-torch.cuda.synchronize() on both sides (R = 1 when K >= 200, else max(5, ceil(200 / K))); the block time is the MAX
+torch.cuda.synchronize() on both sides (R = max(5, ceil(2000 / K)): at least 2 000 timed steps, ~0.2 s of GPU work, so
+that the median block is past the clock ramp of a GPU that was idle when the process started); the block time is the MAX
 over ranks.  `value` = N * K / median(block times); `value_first_block` is the first block alone (a cold GPU: the
 step time falls ~15 % over the first ~20 ms while the clocks ramp); `value_steady` is the median of R more blocks
 after 256 further untimed steps.  All three are on the line, labelled in config.timing.
@@ -276,7 +277,7 @@ def main():
     for _ in range(args.warmup):
         step(counter[0])
         counter[0] += 1
-    repeats = 1 if args.steps >= 200 else max(5, math.ceil(200 / max(args.steps, 1)))
+    repeats = max(5, math.ceil(2000 / max(args.steps, 1)))
     blocks = [timed_block(args.steps) for _ in range(repeats)]
     for _ in range(SETTLE_STEPS):
         step(counter[0])

@@ -82,9 +82,6 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef KURBM_PRIO_LOADER
 #define KURBM_PRIO_LOADER 0
 #endif
-#ifndef KURBM_T16
-#define KURBM_T16 1           // 0: the transposed byte planes leave in 4-byte stores (A/B builds)
-#endif
 #ifndef KURBM_PRIO_ENTRY
 #define KURBM_PRIO_ENTRY 3    // the loader waves' priority from the kernel's first instruction to their first barrier (0: A/B builds)
 #endif
@@ -487,30 +484,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 if (u == 1) { frag_a(acur, 1, fa[1]); frag_b(bcur, 1, 0, fb[0]); }
                 if (u == 2) frag_b(bcur, 1, 1, fb[1]);
                 if (u == 3) frag_b(bcur, 1, 2, fb[2]);
-#ifndef KURBM_BARRIER_AT
-#define KURBM_BARRIER_AT 5
-#endif
-                static_assert(KURBM_BARRIER_AT == 3 || KURBM_BARRIER_AT == 5, "the tile's barrier: behind micro-step 3, or in front of 5");
-                // The tile's ONLY barrier sits behind micro-step 3, the last one that reads this tile (so the loaders may
-                // refill its stage), not at the tile's end: the next tile's first fragments are then read under the MFMAs
-                // of micro-steps 4 and 5 instead of in front of an idle matrix pipe
-                if (KURBM_BARRIER_AT == 5 && u == NU - 1) {
+                // The tile's ONLY barrier sits in front of its last micro-step (behind it the loaders may refill this
+                // stage), and the next tile's first fragments are read right behind it, under the MFMAs of micro-step 5
+                // instead of in front of an idle matrix pipe.  (The barrier behind micro-step 3: no faster, LABBOOK.)
+                if (u == NU - 1) {
                     __syncthreads();
                     __builtin_amdgcn_sched_barrier(0);
-                }
-#ifndef KURBM_NEXT_READ_AT
-#define KURBM_NEXT_READ_AT (KURBM_BARRIER_AT == 5 ? 5 : KURBM_BARRIER_AT + 1)
-#endif
-                if (u == KURBM_NEXT_READ_AT) {
                     frag_a(anext, 0, fa[0], acur);   // (AB: after the second tile of a pair comes the other block)
                     frag_b(bnext, 0, 0, fb[0]);
                 }
                 mfmas(fa[ks & 1], fb[u % 3]);
-                if (KURBM_BARRIER_AT == 3 && u == 3) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    __syncthreads();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 if (AB && (u + 1) % NPB == 0) {   // the NEXT k-step's, behind this step's MFMAs (same registers: not among them)
                     __builtin_amdgcn_sched_barrier(0);
                     expand_a(((u + 1) / NPB) & 1);
@@ -1480,7 +1463,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
 #endif
     // (b) transposed bf16 plane(s) [N][ldoT]: 4 consecutive rows of this lane's column = one 8-byte store;
     //     rows past M (k padding of the statistics GEMM) are written as zeros
-    if (KURBM_T16 && g.outT && g.outT_f8 && TM == 4) {
+    static_assert(TM == 4, "the transposed planes' 4 x 4 lane transpose: four 16-row blocks per wave");
+    if (g.outT && g.outT_f8) {
         // A 0/1 sample as ONE byte per element (fp8 1.0 = 0x38, or 0x40 of a k-permuted byte plane).  A lane holds four bytes
         // (four rows) per 16-row block mi; a 4 x 4 transpose between the block index and the lane's row group (two
         // v_permlane32_swap + two v_permlane16_swap) gives it 16 CONSECUTIVE rows of its column instead: per column of the
@@ -1517,7 +1501,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 }
             }
         }
-    } else if (KURBM_T16 && g.outT && !g.outT_f8 && TM == 4) {
+    } else if (g.outT) {
         // bf16 pieces: the same transpose on the two dwords of a lane's four rows -- 16 consecutive rows = 32 bytes per lane and
         // piece, a whole 128-byte line per column of the wave's tile in two 16-byte stores where there were four 8-byte ones
         const int np = (g.outT_pieces == 3) ? 3 : 1;
@@ -1557,45 +1541,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                     uint16_t* dst = g.outT + (size_t)j * g.outT_plane + (size_t)col * g.ldoT + rq16;
                     *reinterpret_cast<u32x4*>(dst) = u32x4{px[0], py[0], px[1], py[1]};
                     *reinterpret_cast<u32x4*>(dst + 8) = u32x4{px[2], py[2], px[3], py[3]};
-                }
-            }
-        }
-    } else if (g.outT) {
-        const int np = (g.outT_pieces == 3) ? 3 : 1;
-        const float tsign = g.outT_neg ? -1.f : 1.f;   // (the pieces of -x are minus the pieces of x)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int col = colb + ni * 16;
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const int rb = rowq + mi * 16;
-                if (col < g.N && rb < g.ldoT) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (rb + r < g.M) ? tsign * xv[mi][ni][r] : 0.f;
-                    if (g.outT_f8 == 2) {   // ... as four bytes of a k-permuted byte plane (0x40 = one; kurbm_device.h kperm64:
-                                            // four consecutive k from a multiple of four stay consecutive), row stride as for bf16
-                        *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(g.outT) + (size_t)col * g.ldoT * 2 + kperm64(rb)) =
-                            (v[0] != 0.f ? 0x40u : 0u) | (v[1] != 0.f ? 0x4000u : 0u) | (v[2] != 0.f ? 0x400000u : 0u) |
-                            (v[3] != 0.f ? 0x40000000u : 0u);
-                        continue;
-                    }
-                    if (g.outT_f8) {   // a 0/1 sample as four fp8 bytes (1.0 = 0x38), row stride as for bf16
-                        *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(g.outT) + (size_t)col * g.ldoT * 2 + rb) =
-                            (v[0] != 0.f ? 0x38u : 0u) | (v[1] != 0.f ? 0x3800u : 0u) | (v[2] != 0.f ? 0x380000u : 0u) |
-                            (v[3] != 0.f ? 0x38000000u : 0u);
-                        continue;
-                    }
-                    uint16_t* dst = g.outT + (size_t)col * g.ldoT + rb;
-                    for (int j = 0; j < np; ++j) {
-                        u32x2 pk;
-                        pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-                        *reinterpret_cast<u32x2*>(dst + j * g.outT_plane) = pk;
-                        if (j + 1 < np) {   // residual of the piece just written: exact in fp32
-                            v[0] -= bf16_bits_to_f32(pk.x & 0xFFFFu); v[1] -= bf16_bits_to_f32(pk.x >> 16);
-                            v[2] -= bf16_bits_to_f32(pk.y & 0xFFFFu); v[3] -= bf16_bits_to_f32(pk.y >> 16);
-                        }
-                    }
                 }
             }
         }
