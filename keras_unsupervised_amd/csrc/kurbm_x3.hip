@@ -1590,32 +1590,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256, (64 * WAVES_M * WAVES
                 *reinterpret_cast<u32x4*>(plane + (size_t)gr * g.ldo + gc) = *reinterpret_cast<const u32x4*>(smem + row * PROWB + 16 * c);
         }
     } else if (g.out) {
+        // Each lane rounds its own four rows of a column to bf16 first (two packed dwords: rows 0|1 and 2|3), trades them with the
+        // neighbouring column's lane (DPP) and picks the two halves of one row with a v_perm_b32: three instructions per dword of
+        // the patch.  The residual for the next piece comes from the same packed dwords.  (As float selects around the swap and a
+        // pack per dword this phase was ~20 instructions per dword: 14 800 cycles of the Gaussian h -> v launch, stamps of round 4.)
         const int odd = l15 & 1;
+        const uint32_t sel = odd ? 0x03020706u : 0x05040100u;   // {neighbour | own}: odd lane (nb.hi, own.hi), even lane (own.lo, nb.lo)
         const int npc = (g.out_pieces == 3) ? 3 : 1;     // a real-valued plane leaves as its three exact pieces
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)                  // columns past N (k padding of the next GEMM): zeros
+            if (!(colb + ni * 16 < g.N)) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xv[mi][ni][r] = 0.f;
+            }
         for (int j = 0; j < npc; ++j) {
             if (j > 0) __syncthreads();                   // the previous piece has left the patch
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
-                const bool col_ok = colb + ni * 16 < g.N;
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float mine = col_ok ? (odd ? xv[mi][ni][2 * h + 1] : xv[mi][ni][2 * h]) : 0.f;
-                        const float send = col_ok ? (odd ? xv[mi][ni][2 * h] : xv[mi][ni][2 * h + 1]) : 0.f;
-                        const float recv = pair_swap(send);
-                        const uint32_t pk = odd ? pack_bf16x2(recv, mine) : pack_bf16x2(mine, recv);
-                        *reinterpret_cast<uint32_t*>(smem + (wm * WM + mi * 16 + slot * 4 + 2 * h + odd) * PROW16 +
-                                                     2 * (wn * WN + ni * 16 + (l15 & ~1))) = pk;
+                for (int mi = 0; mi < TM; ++mi) {
+                    float (&x)[4] = xv[mi][ni];
+                    const uint32_t p01 = pack_bf16x2(x[0], x[1]), p23 = pack_bf16x2(x[2], x[3]);
+                    const uint32_t n01 = (uint32_t)__builtin_amdgcn_mov_dpp((int)p01, 0xB1, 0xF, 0xF, true);
+                    const uint32_t n23 = (uint32_t)__builtin_amdgcn_mov_dpp((int)p23, 0xB1, 0xF, 0xF, true);
+                    unsigned char* dst = smem + (wm * WM + mi * 16 + slot * 4 + odd) * PROW16 + 2 * (wn * WN + ni * 16 + (l15 & ~1));
+                    *reinterpret_cast<uint32_t*>(dst) = __builtin_amdgcn_perm(n01, p01, sel);                // row 0 (even lane) / 1 (odd)
+                    *reinterpret_cast<uint32_t*>(dst + 2 * PROW16) = __builtin_amdgcn_perm(n23, p23, sel);   // row 2 / 3
+                    if (j + 1 < npc) {   // residual of the piece just written: exact in fp32
+                        x[0] -= __uint_as_float(p01 << 16); x[1] -= __uint_as_float(p01 & 0xFFFF0000u);
+                        x[2] -= __uint_as_float(p23 << 16); x[3] -= __uint_as_float(p23 & 0xFFFF0000u);
                     }
-            }
-            if (j + 1 < npc) {   // residual of the piece just written: exact in fp32
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) xv[mi][ni][r] -= bf16_bits_to_f32(f32_to_bf16_bits(xv[mi][ni][r]));
+                }
             }
             __syncthreads();
             constexpr int CH = BN / 8;   // 16-B chunks per row
