@@ -429,9 +429,28 @@ def main():
         except Exception:
             traffic_all, pmc_all = {}, {}
         if args.compute == "x3":
-            dom = max(x3_units, key=lambda k: kern_x3[k]["ms"])
+            # The dominant KERNEL, as `rocprofv3 --stats` sees it: both sampling half steps are launches of one kernel (one row of
+            # kernel_stats.csv, its average over both), so they compete as their mean -- not the slower launch of the pair alone
+            symbols = {"x3_half_step_vh_sample": "k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true, false>",
+                       "x3_half_step_hv_sample": "k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 1, true, false>",
+                       "x3_half_step_vh_prob": "k_gemm_pb<256, 64, 4, 2, 64, 3, 0, 0, true, false>",
+                       "x3_stats_gemm": "k_gemm_pb<256, 64, 4, 2, 64, 3, 1, 0, true, false>"}
+            pair = ["x3_half_step_vh_sample", "x3_half_step_hv_sample"]
+            if all(k in kern_x3 for k in pair):
+                ms2 = sum(kern_x3[k]["ms"] for k in pair) / 2
+                e = dict(kern_x3[pair[0]])
+                scale = e["ms"] / ms2
+                e.update(ms=ms2, executed_tflops=e["executed_tflops"] * scale, algorithmic_tflops=e["algorithmic_tflops"] * scale,
+                         frac_of_mfma_roof=e["mfma_roof_ms"] / ms2, launches=pair)
+                kern_x3["x3_half_step_sample_both_launches"] = e
+                symbols["x3_half_step_sample_both_launches"] = symbols[pair[0]]
+                cand = [k for k in x3_units if k not in pair] + ["x3_half_step_sample_both_launches"]
+            else:
+                cand = list(x3_units)
+            dom = max(cand, key=lambda k: kern_x3[k]["ms"])
+            dom_pmc = pair[1] if dom == "x3_half_step_sample_both_launches" else dom
             step16, step8 = (12, 1) if f8pos else (13, 0)
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": kern_x3[dom]["executed_tflops"],
+            roofline = {"bound": "mfma", "kernel": dom, "kernel_symbol": symbols.get(dom), "achieved": kern_x3[dom]["executed_tflops"],
                         "peak": kern_x3[dom]["executed_tflops"] / kern_x3[dom]["frac_of_mfma_roof"], "unit": "TFLOP/s",
                         "frac": kern_x3[dom]["frac_of_mfma_roof"],
                         "frac_algorithmic": kern_x3[dom]["algorithmic_tflops"] / PEAK_BF16_MFMA_TFLOPS,
@@ -441,12 +460,12 @@ def main():
                                 "v_pos^T h_pos, 0/1 x 0/1, one unit on the fp8 matrix cores + three bf16 units for v_neg^T h_neg; one unit = "
                                 "2 B V H) over the launch duration (HIP events, this run); peak = that flop over the time its MFMAs "
                                 "take at the dense peaks of their types (bf16 2.5, fp8 5.0 PFLOP/s), frac = that time / the duration",
-                        "traffic": traffic_all.get(dom, {}).get("hbm_bytes_per_launch"),
+                        "traffic": traffic_all.get(dom_pmc, {}).get("hbm_bytes_per_launch"),
                         "traffic_source": "%s (rocprofv3 --pmc passes of an earlier run of this command; not measured in this run)" % traffic_file,
-                        "mfma_busy": pmc_all.get(dom, {}).get("mfma_busy_share"),
-                        "wait_any": pmc_all.get(dom, {}).get("wait_any_share"),
-                        "l2_hit_rate": pmc_all.get(dom, {}).get("l2_hit_rate"),
-                        "counters_source": "%s (SQ / TCC counter passes of tools/round3_profile.sh on the same kernels; not measured in this run)" % pmc_file,
+                        "mfma_busy": pmc_all.get(dom_pmc, {}).get("mfma_busy_share"),
+                        "wait_any": pmc_all.get(dom_pmc, {}).get("wait_any_share"),
+                        "l2_hit_rate": pmc_all.get(dom_pmc, {}).get("l2_hit_rate"),
+                        "counters_source": "%s (SQ / TCC counter passes of tools/profile_round.sh on the same kernels; not measured in this run)" % pmc_file,
                         "step": {"executed_tflops": X3_UNITS["binary"] * BVH2 / (ms_per_step * 1e-3) / 1e12 * world,
                                  "frac": mfma_roof_ms(step16, step8) / ms_per_step,
                                  "note": "all 13 GEMM units of a step (%d bf16 + %d fp8): the time their MFMAs take at the dense peaks "
@@ -456,7 +475,7 @@ def main():
             dom = max(kern, key=lambda k: kern[k]["ms"])
             roofline = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": kern[dom]["frac"],
-                        "traffic": traffic_all.get(dom, {}).get("hbm_bytes_per_launch"),
+                        "traffic": traffic_all.get(dom_pmc, {}).get("hbm_bytes_per_launch"),
                         "traffic_source": "%s (rocprofv3 --pmc passes of an earlier run; not measured in this run)" % traffic_file,
                         "step": {"algorithmic_tflops": FLOP_STEP / (ms_per_step * 1e-3) / 1e12 * world,
                                  "frac": FLOP_STEP / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
