@@ -87,11 +87,15 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
     }
     if (!outT && !colpart) return;
     __syncthreads();
-    if (colpart && t < CVT && r0 < rows && c0 + t < cols) {   // out-of-range elements were staged as zeros
+    if (colpart) {   // out-of-range elements were staged as zeros.  Four lanes per column, a quarter of the rows each (one wave's
+                     // chain of TR dependent LDS reads was 2 us of this launch), combined in a fixed order: (q0 + q1) + (q2 + q3)
+        const int cc = t >> 2, part = t & 3;
         float s = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < TR; ++i) s += tile[i][t];
-        colpart[(size_t)blockIdx.y * ld_colpart + c0 + t] = s;
+#pragma unroll
+        for (int i = 0; i < TR / 4; ++i) s += tile[part * (TR / 4) + i][cc];
+        s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+        s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+        if (part == 0 && r0 < rows && c0 + cc < cols) colpart[(size_t)blockIdx.y * ld_colpart + c0 + cc] = s;
     }
     if (!outT) return;
     // TR / 4 lanes x 4 rows across a column of the tile, 1024 / TR columns per pass
@@ -110,6 +114,67 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ i
         if (c < outT_rows && r < ldoT)                    // ldoT % 8 == 0
             store3(outT + (size_t)c * ldoT + r, outT_plane, tile[rr4 + 0][cq + CPP * j], tile[rr4 + 1][cq + CPP * j],
                    tile[rr4 + 2][cq + CPP * j], tile[rr4 + 3][cq + CPP * j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 0/1 data: fp32 [rows][ld_in] -> the k-permuted byte plane (0x40 = one; kperm64) and / or the transposed fp8 plane (0x38 = one)
+// ------------------------------------------------------------------------------------
+// The planes a 0/1 batch travels as on the x3 path (kurbm_x3_convert_rows, and every step of a first epoch).  64 x 64 elements per
+// workgroup: a thread loads a 4 x 4 block (four 16-byte loads), writes its four row dwords into a row image and its four column
+// dwords into a column image in LDS, and every global store is 16 bytes -- a row of the tile is one 64-byte run in either plane.
+// (k_f32_to_bf16 wrote both planes in 4-byte stores and summed a column in one wave's chain of 64 LDS reads: 10 us for 19 MB.)
+// Out-of-range source elements read as zero: the k padding of both planes is written here.  colpart (nullable): the column sums
+// of each 64-row band -- counts of ones, exact in any order.
+__global__ __launch_bounds__(256) void k_f32_to_planes01(const float* __restrict__ in, int rows, int cols, int ld_in,
+                                                         unsigned char* __restrict__ out, int ldo, int out_rows,
+                                                         unsigned char* __restrict__ outT, int ldoT, int outT_rows,
+                                                         float* __restrict__ colpart, int ld_colpart) {
+    constexpr int PR = 80, PC = 68;   // image pitches (bytes): 16-byte rows for the row image; 17 dwords for the column image, whose
+                                      // writes then fall on 32 different banks (80: on two)
+    __shared__ __attribute__((aligned(16))) unsigned char rimg[64 * PR];
+    __shared__ __attribute__((aligned(16))) unsigned char cimg[64 * PC];
+    const int t = threadIdx.x;
+    const int q4 = (t & 15) * 4, r4 = (t >> 4) * 4;       // this thread's 4 x 4 block of the tile
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    uint32_t colw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + r4 + i, c = c0 + q4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows && c < cols) {      // ld_in % 4 == 0 and c % 4 == 0: the 16-byte load stays inside the row
+            v = *reinterpret_cast<const f32x4*>(in + (size_t)r * ld_in + c);
+            if (c + 1 >= cols) v.y = 0.f;
+            if (c + 2 >= cols) v.z = 0.f;
+            if (c + 3 >= cols) v.w = 0.f;
+        }
+        const bool b0 = v.x != 0.f, b1 = v.y != 0.f, b2 = v.z != 0.f, b3 = v.w != 0.f;
+        *reinterpret_cast<uint32_t*>(rimg + (r4 + i) * PR + kperm64(q4)) =      // (q4 % 4 == 0: four consecutive k stay consecutive)
+            (b0 ? 0x40u : 0u) | (b1 ? 0x4000u : 0u) | (b2 ? 0x400000u : 0u) | (b3 ? 0x40000000u : 0u);
+        const uint32_t one = 0x38u << (8 * i);
+        colw[0] |= b0 ? one : 0u; colw[1] |= b1 ? one : 0u; colw[2] |= b2 ? one : 0u; colw[3] |= b3 ? one : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<uint32_t*>(cimg + (q4 + k) * PC + r4) = colw[k];
+    __syncthreads();
+    const int line = t >> 2, part = t & 3;   // a row of the row image / a column of the column image, 16 bytes of it
+    if (out) {
+        const int r = r0 + line, c = c0 + 16 * part;
+        if (r < out_rows && c < ldo)         // (ldo % 64 == 0, the launcher checks: whole k-permuted groups)
+            *reinterpret_cast<u32x4*>(out + (size_t)r * ldo + c) = *reinterpret_cast<const u32x4*>(rimg + line * PR + 16 * part);
+    }
+    if (outT || colpart) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(cimg + line * PC + 16 * part);
+        const u32x4 x = {src[0], src[1], src[2], src[3]};
+        const int c = c0 + line, r = r0 + 16 * part;
+        if (outT && c < outT_rows && r < ldoT)   // row stride as for bf16 (2 ldoT bytes), the first ldoT of them used
+            *reinterpret_cast<u32x4*>(outT + (size_t)c * ldoT * 2 + r) = x;
+        if (colpart) {
+            int n = __popc(x.x & 0x08080808u) + __popc(x.y & 0x08080808u) + __popc(x.z & 0x08080808u) + __popc(x.w & 0x08080808u);
+            n += __builtin_amdgcn_mov_dpp(n, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+            n += __builtin_amdgcn_mov_dpp(n, 0x4E, 0xF, 0xF, true);   // lane ^ 2
+            if (part == 0 && r0 < rows && c < cols) colpart[(size_t)blockIdx.y * ld_colpart + c] = (float)n;
+        }
     }
 }
 
@@ -332,6 +397,13 @@ hipError_t launch_f32_to_bf16(const float* in, int rows, int cols, int ld_in, ui
     int r_ext = rows, c_ext = cols;
     if (out) { if (out_rows > r_ext) r_ext = out_rows; if (ldo > c_ext) c_ext = ldo; }
     if (outT) { if (ldoT > r_ext) r_ext = ldoT; if (outT_rows > c_ext) c_ext = outT_rows; }
+    // 0/1 data as a byte plane and / or an fp8 transposed plane: the 16-byte-store kernel
+    if (pieces == 1 && (out || outT) && (!out || out_bytes) && (!outT || outT_f8 == 1) && (!out || ldo % 64 == 0) && (!outT || ldoT % 8 == 0)) {
+        dim3 grid((c_ext + 63) / 64, (r_ext + 63) / 64);
+        hipLaunchKernelGGL(k_f32_to_planes01, grid, dim3(256), 0, st, in, rows, cols, ld_in, reinterpret_cast<unsigned char*>(out), ldo,
+                           out_rows, reinterpret_cast<unsigned char*>(outT), ldoT, outT_rows, colpart, ld_colpart);
+        return hipGetLastError();
+    }
     // colpart bands are 64 rows, so a launch that wants them keeps 64-row tiles
     const bool small = !colpart && ((c_ext + CVT - 1) / CVT) * ((r_ext + CVT - 1) / CVT) < 512;
     if (small) {
