@@ -185,11 +185,13 @@ static OuterPlan plan_outer(const kurbm_ctx* ctx, int rows, int n_vis, int n_hid
 
 struct Workspace {
     float *h_pos, *h_neg, *h_tmp, *v_neg, *part_h, *part_v, *slab;
+    float *small_t;   // kurbm_cd_step_small's transposed planes (rows <= SMALL_ROWS_MAX only)
     int ldh, ldv, ld_part_h, ld_part_v, max_row_tiles;
     size_t slab_stride, bytes;
 };
 
 static size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
+constexpr int SMALL_ROWS_MAX = 512;   // batches up to here carry the transposed planes of the one-launch step in their workspace
 
 static Workspace carve(const kurbm_ctx* ctx, void* base, int rows, int n_vis, int n_hid, int k) {
     Workspace w;
@@ -210,6 +212,7 @@ static Workspace carve(const kurbm_ctx* ctx, void* base, int rows, int n_vis, in
     w.part_h = take((size_t)w.max_row_tiles * w.ld_part_h);
     w.part_v = take((size_t)w.max_row_tiles * w.ld_part_v);
     w.slab = take(w.slab_stride * pl.nsplit_bound);
+    w.small_t = rows <= SMALL_ROWS_MAX ? take((size_t)(2 * n_hid + n_vis) * round_up(rows, 16)) : nullptr;
     (void)k;
     // free energy: row partials [col tiles][round_up(rows,4)] alias the front of the workspace
     const size_t fe = align_up((size_t)ceil_div(n_hid, 64) * round_up(rows, 4) * 4);
@@ -502,7 +505,10 @@ int kurbm_cd_step_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_ba
     memset(&a, 0, sizeof a);
     a.W = p->W; a.b_h = p->b_h; a.b_v = p->b_v; a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw;
     a.v = v_batch; a.rows = rows; a.ldv = ldv;
+    if (rows > SMALL_ROWS_MAX) return fail(KURBM_ERR_UNSUPPORTED, "kurbm_cd_step_small: at most %d rows per batch", SMALL_ROWS_MAX);
     a.h_pos = w.h_pos; a.h_neg = w.h_neg; a.v_neg = w.v_neg; a.ldh = w.ldh; a.ldn = w.ldv;
+    a.ldt = round_up(rows, 16);
+    a.h_posT = w.small_t; a.h_negT = a.h_posT + (size_t)p->n_hid * a.ldt; a.v_negT = a.h_negT + (size_t)p->n_hid * a.ldt;
     a.bar = ctx->status + 64; a.status = ctx->status;
     a.timeout_ticks = 200000000ull;          // 2 s of the 100 MHz clock: only a grid that is not resident ever gets there
     const uint32_t base = o->chain * 64u;
@@ -513,7 +519,7 @@ int kurbm_cd_step_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_ba
     // than the CUs -- the grid must be resident, one workgroup per CU
     const int tm = ceil_div(rows, 16), tv = ceil_div(p->n_vis, 16), th = ceil_div(p->n_hid, 16);
     int nblk = tm * th > tm * tv ? tm * th : tm * tv;
-    const int stat = ceil_div(tv * th + tv + th, 4);
+    const int stat = ceil_div(tv * th + tv + th, 8);   // (eight waves per workgroup: kurbm_small.hip SMALL_WAVES)
     if (stat > nblk) nblk = stat;
     if (nblk > ctx->ncu) nblk = ctx->ncu;
     if (nblk > 1024) nblk = 1024;

@@ -340,11 +340,12 @@ struct SmallArgs {
     float* W; float* b_h; float* b_v;
     const float* v;
     float* h_pos; float* v_neg; float* h_neg;     // workspace planes [rows][ldh] / [rows][ldn]
+    float* h_posT; float* v_negT; float* h_negT;  // ... and transposed: [n_hid][ldt] / [n_vis][ldt], ldt = the batch rounded up to 16
     unsigned* bar;                                 // the grid barrier's words in the context's status block (kurbm_small.hip: grid_barrier)
     unsigned* status;
     unsigned long long timeout_ticks;              // of the 100 MHz constant clock
     RngArgs rng_h, rng_v;                          // the counters of the h_pos and v_neg sampling sites
-    int n_vis, n_hid, ldw, rows, ldv, ldh, ldn;
+    int n_vis, n_hid, ldw, rows, ldv, ldh, ldn, ldt;
     int which, gauss;
     float lr;
 };

@@ -6,11 +6,13 @@
 // v_neg sample, h_neg probabilities, dW / db_h / db_v applied -- is one grid-resident kernel of four phases with a device-scope
 // barrier between them (sense-reversing: a wrapping arrival counter and a generation word in the context's status block; every
 // wait is bounded and reports through kurbm_ctx_status instead of hanging):
-//   1  h_pos = (u < act(v . W + b_h))            one 16 x 16 output tile per workgroup pass, its four waves split k
+//   1  h_pos = (u < act(v . W + b_h))            one 16 x 16 output tile per workgroup pass, its eight waves split k
 //   2  v_neg = (u < sigmoid(h_pos . W^T + b_v))  or  loc + N(0, 1)   (Gaussian visibles: Box-Muller of two Philox planes)
 //   3  h_neg = sigmoid(v_neg . W + b_h)
 //   4  W += lr (v_pos^T h_pos - v_neg^T h_neg): one 16 x 16 tile of W per WAVE, k = the batch, applied from the accumulators (no
-//      slabs); the bias column sums by waves of their own, fixed order (bit-reproducible)
+//      slabs); the bias column sums by waves of their own, fixed order (bit-reproducible).  Phases 1-3 leave their planes
+//      TRANSPOSED as well ([unit][batch row]: the four rows a lane holds are one 16-byte store), so that k = the batch is
+//      contiguous here: 16-byte loads instead of four strided dwords per operand and chunk
 // Products on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fma chains, like kurbm_kernels.hip), operands straight
 // from L2 -- the whole problem is a few MB -- with the same k-slot permutation trick: a lane's four consecutive k feed four
 // successive MFMAs.  Same Philox counters as every other path (include/kurbm.h), so the draws are the oracle's; the sums are
@@ -82,6 +84,11 @@ __device__ __forceinline__ f32x4 ld_plane4(const float* base, unsigned byte_off)
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d, (int)byte_off, 0, 16));
 }
 
+__device__ __forceinline__ void st_plane4(float* base, unsigned byte_off, f32x4 v) {
+    const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFF, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, v), d, (int)byte_off, 0, 16);
+}
+
 // One 16 x 16 tile of C = A . B over the k chunks [c0, c1) of 16 (stride cs): the lane (x = lane & 15, slot = lane >> 4) feeds
 // k = 16 c + 4 slot + e to MFMA e of a chunk -- A and B agree on that map, so any operand layout works:
 //   KC (k contiguous in memory):  one 16-byte load per chunk      X[x][k]  = base[x * ld + k]
@@ -117,10 +124,13 @@ __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A
                 for (int e = 0; e < 4; ++e) av[u][e] = (live && a_ok && k + e < K) ? (A_PL ? ld_plane(A + (size_t)(k + e) * lda + x) : A[(size_t)(k + e) * lda + x]) : 0.f;
             }
             if (B_KC) {
-                if (live && b_ok && k + 3 < K) { const f32x4 t = *reinterpret_cast<const f32x4*>(B + (size_t)x * ldb + k); bv[u][0] = t.x; bv[u][1] = t.y; bv[u][2] = t.z; bv[u][3] = t.w; }
+                if (live && b_ok && k + 3 < K) {
+                    const f32x4 t = B_PL ? ld_plane4(B, 4u * (unsigned)(x * ldb + k)) : *reinterpret_cast<const f32x4*>(B + (size_t)x * ldb + k);
+                    bv[u][0] = t.x; bv[u][1] = t.y; bv[u][2] = t.z; bv[u][3] = t.w;
+                }
                 else
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[u][e] = (live && b_ok && k + e < K) ? B[(size_t)x * ldb + k + e] : 0.f;
+                    for (int e = 0; e < 4; ++e) bv[u][e] = (live && b_ok && k + e < K) ? (B_PL ? ld_plane(B + (size_t)x * ldb + k + e) : B[(size_t)x * ldb + k + e]) : 0.f;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[u][e] = (live && b_ok && k + e < K) ? (B_PL ? ld_plane(B + (size_t)(k + e) * ldb + x) : B[(size_t)(k + e) * ldb + x]) : 0.f;
@@ -133,12 +143,14 @@ __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A
     }
 }
 
-// A half step over all 16 x 16 tiles of out [rows][N]: a workgroup takes tiles blockIdx.x, + gridDim.x, ...; its four waves
-// split the k chunks and meet in LDS (added in wave order); wave 0 finishes the tile: bias, activation, draw, store.
+// A half step over all 16 x 16 tiles of out [rows][N]: a workgroup takes tiles blockIdx.x, + gridDim.x, ...; its eight waves
+// split the k chunks and meet in LDS (added in wave order); wave 0 finishes the tile: bias, activation, draw, store -- row-major
+// into `out` (nullable) and transposed into outT [N][ldt] (rows of the tile past the batch as zeros: phase 4 reads whole chunks).
 // HV = false: out = f(in . W + b_h) (k = visible units, W read as [k][n]); HV = true: out = f(in . W^T + b_v) (W read as [n][k]).
+constexpr int SMALL_WAVES = 8;
 template <bool HV, bool IN_PL>
-__device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in, int ld_in, float* __restrict__ out, int ldo, int act,
-                                int noise, const RngArgs& rng, float* red) {
+__device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in, int ld_in, float* __restrict__ out, int ldo,
+                                float* __restrict__ outT, int act, int noise, const RngArgs& rng, float* red) {
     const int K = HV ? a.n_hid : a.n_vis, N = HV ? a.n_vis : a.n_hid;
     const float* bias = HV ? a.b_v : a.b_h;
     const int tiles_m = (a.rows + 15) / 16, tiles_n = (N + 15) / 16, nch = (K + 15) / 16;
@@ -148,14 +160,14 @@ __device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in
         const int m = tm * 16 + x, n = tn * 16 + x;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* At = in + (size_t)tm * 16 * ld_in;                                      // rows of the batch, k contiguous
-        if (HV) tile_mma<true, true, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + (size_t)tn * 16 * a.ldw, a.ldw, n < N, K, wave, nch, 4, x, slot);   // W^T: rows = visible units
-        else    tile_mma<true, false, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + tn * 16, a.ldw, n < N, K, wave, nch, 4, x, slot);                 // W as [k][n]
+        if (HV) tile_mma<true, true, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + (size_t)tn * 16 * a.ldw, a.ldw, n < N, K, wave, nch, SMALL_WAVES, x, slot);   // W^T: rows = visible units
+        else    tile_mma<true, false, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + tn * 16, a.ldw, n < N, K, wave, nch, SMALL_WAVES, x, slot);                 // W as [k][n]
         *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc;
         __syncthreads();
         if (wave == 0) {
             f32x4 s = *reinterpret_cast<const f32x4*>(red + lane * 4);
 #pragma unroll
-            for (int q = 1; q < 4; ++q) s += *reinterpret_cast<const f32x4*>(red + (q * 64 + lane) * 4);
+            for (int q = 1; q < SMALL_WAVES; ++q) s += *reinterpret_cast<const f32x4*>(red + (q * 64 + lane) * 4);
             const int col = tn * 16 + x, row0 = tm * 16 + 4 * slot;     // C layout: lane holds rows row0 .. row0 + 3 of column col
             if (col < N) {
                 const float b = bias[col];
@@ -164,6 +176,7 @@ __device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in
                 if (noise != NOISE_NONE) philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), rng.stream_id, rng.step, rng.seed_lo, rng.seed_hi, w1);
                 if (noise == NOISE_GAUSSIAN)
                     philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), rng.stream_id | 0x80000000u, rng.step, rng.seed_lo, rng.seed_hi, w2);
+                f32x4 yt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float xv = s[r] + b;
@@ -171,16 +184,20 @@ __device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in
                     float y = p;
                     if (noise == NOISE_BERNOULLI) y = (u32_to_unit(w1[r]) < p) ? 1.f : 0.f;
                     else if (noise == NOISE_GAUSSIAN) y = p + box_muller(u32_to_unit(w1[r]), u32_to_unit(w2[r]));
-                    if (row0 + r < a.rows) st_plane(out + (size_t)(row0 + r) * ldo + col, y);
+                    if (row0 + r < a.rows) {
+                        if (out) st_plane(out + (size_t)(row0 + r) * ldo + col, y);
+                        yt[r] = y;
+                    }
                 }
+                if (outT) st_plane4(outT, 4u * (unsigned)(col * a.ldt + row0), yt);
             }
         }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 64 * 4];
+__global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[SMALL_WAVES * 64 * 4];
     unsigned gen = 0;
     if (threadIdx.x == 0) gen = __hip_atomic_load(a.bar + 16 * 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     gen = __builtin_amdgcn_readfirstlane(gen);   // (only thread 0 uses it; uniform for tidiness)
@@ -193,17 +210,17 @@ __global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
 #endif
     KURBM_SST(0);
     // 1: h_pos ~ p(h | v_pos)                                                   rbm.py:120
-    half_step_small<false, false>(a, a.v, a.ldv, a.h_pos, a.ldh, act_h, NOISE_BERNOULLI, a.rng_h, red);
+    half_step_small<false, false>(a, a.v, a.ldv, a.h_pos, a.ldh, a.h_posT, act_h, NOISE_BERNOULLI, a.rng_h, red);
     KURBM_SST(1);
     ok = grid_barrier(a, gen) && ok;
     KURBM_SST(2);
     // 2: v_neg ~ p(v | h_pos)                                                   rbm.py:121-123 / :143-144
-    if (ok) half_step_small<true, true>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red);
+    if (ok) half_step_small<true, true>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, a.v_negT, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red);
     KURBM_SST(3);
     ok = grid_barrier(a, gen) && ok;
     KURBM_SST(4);
     // 3: h_neg = sigmoid(v_neg . W + b_h): probabilities in both modes          rbm.py:124 / :145
-    if (ok) half_step_small<false, true>(a, a.v_neg, a.ldn, a.h_neg, a.ldh, ACT_SIGMOID, NOISE_NONE, a.rng_h, red);
+    if (ok) half_step_small<false, true>(a, a.v_neg, a.ldn, nullptr, 0, a.h_negT, ACT_SIGMOID, NOISE_NONE, a.rng_h, red);
     KURBM_SST(5);
     ok = grid_barrier(a, gen) && ok;
     KURBM_SST(6);
@@ -215,41 +232,48 @@ __global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
     const int lane = threadIdx.x & 63, x = lane & 15, slot = lane >> 4;
     const int tiles_v = (a.n_vis + 15) / 16, tiles_h = (a.n_hid + 15) / 16, nch = (a.rows + 15) / 16;
     const int n_w = (a.which & 1) ? tiles_v * tiles_h : 0, n_bh = (a.which & 2) ? tiles_h : 0, n_bv = (a.which & 4) ? tiles_v : 0;
-    const int nwaves = gridDim.x * 4;
-    for (int task = blockIdx.x * 4 + (threadIdx.x >> 6); task < n_w + n_bh + n_bv; task += nwaves) {
+    const int nwaves = gridDim.x * SMALL_WAVES;
+    for (int task = blockIdx.x * SMALL_WAVES + (threadIdx.x >> 6); task < n_w + n_bh + n_bv; task += nwaves) {
         if (task < n_w) {
             const int ti = task / tiles_h, tj = task - ti * tiles_h;
             const int i = ti * 16 + x, j = tj * 16 + x;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            // dW = v_pos^T . h_pos - v_neg^T . h_neg   (rbm.py:125-126), k = the batch rows: both operands k-strided
-            // (one batch of loads per phase.  Both phases' 128 guarded loads in ONE batch: 15.0 against 8.3 us for this phase -- measured)
-            tile_mma<false, false, false, false, true>(acc, a.v + ti * 16, a.ldv, i < a.n_vis, a.h_pos + tj * 16, a.ldh, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
-            tile_mma<false, false, true, true, true>(acc, a.v_neg + ti * 16, a.ldn, i < a.n_vis, a.h_neg + tj * 16, a.ldh, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+            // dW = v_pos^T . h_pos - v_neg^T . h_neg   (rbm.py:125-126), k = the batch rows: contiguous in the transposed planes, strided
+            // in the data.  (One batch of loads per product.  Both products' loads in ONE batch: 15.0 against 8.3 us for this phase.)
+            tile_mma<false, true, false, false, true>(acc, a.v + ti * 16, a.ldv, i < a.n_vis, a.h_posT + (size_t)tj * 16 * a.ldt, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+            tile_mma<true, true, true, true, true>(acc, a.v_negT + (size_t)ti * 16 * a.ldt, a.ldt, i < a.n_vis, a.h_negT + (size_t)tj * 16 * a.ldt, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
             const int col = tj * 16 + x, row0 = ti * 16 + 4 * slot;
             if (col < a.n_hid)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (row0 + r < a.n_vis) a.W[(size_t)(row0 + r) * a.ldw + col] += a.lr * acc[r];      // rbm.py:127-128
         } else {
-            // a bias group: lane (column x, row group slot) adds rows slot, slot + 4, ... (eight loads in flight), then the four
-            // row groups meet by shuffles, ((g0 + g1) + (g2 + g3)): a fixed order
+            // a bias group: lane (column x, row group slot) adds rows 16 e + 4 slot .. + 3 of its column for e = 0, 1, ... (16-byte loads
+            // from the transposed planes, whose rows past the batch are zeros; the data itself is row-major: dwords), then the four row
+            // groups meet by shuffles, ((g0 + g1) + (g2 + g3)): a fixed order
             const bool hid = task < n_w + n_bh;
             const int g = hid ? task - n_w : task - n_w - n_bh;
             const int col = g * 16 + x, N = hid ? a.n_hid : a.n_vis;
-            const float* pos = hid ? a.h_pos : a.v;
-            const float* neg = hid ? a.h_neg : a.v_neg;
-            const int ldp = hid ? a.ldh : a.ldv, ldq = hid ? a.ldh : a.ldn;
+            const float* posT = hid ? a.h_posT : nullptr;
+            const float* negT = hid ? a.h_negT : a.v_negT;
             float s = 0.f;
             if (col < N)
-                for (int r0 = slot; r0 < a.rows; r0 += 32) {
-                    float d[8];
+                for (int r0 = 4 * slot; r0 < a.rows; r0 += 64) {
+                    f32x4 pq[4], nq[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int r = r0 + 4 * e;
-                        d[e] = r < a.rows ? (hid ? ld_plane(pos + (size_t)r * ldp + col) : pos[(size_t)r * ldp + col]) - ld_plane(neg + (size_t)r * ldq + col) : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = r0 + 16 * e;
+                        const bool live = r < a.rows;
+                        nq[e] = live ? ld_plane4(negT, 4u * (unsigned)(col * a.ldt + r)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (hid) pq[e] = live ? ld_plane4(posT, 4u * (unsigned)(col * a.ldt + r)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        else
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) pq[e][q] = (r + q < a.rows) ? a.v[(size_t)(r + q) * a.ldv + col] : 0.f;
                     }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s += d[e];
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) s += pq[e][q] - nq[e][q];
                 }
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
@@ -263,7 +287,7 @@ __global__ __launch_bounds__(256) void k_cd1_small(SmallArgs a) {
 }
 
 hipError_t launch_cd1_small(const SmallArgs& a, int nblk, hipStream_t st) {
-    hipLaunchKernelGGL(k_cd1_small, dim3(nblk), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_cd1_small, dim3(nblk), dim3(64 * SMALL_WAVES), 0, st, a);
     return hipGetLastError();
 }
 
