@@ -119,8 +119,9 @@ int kurbm_ctx_set_option(kurbm_ctx* ctx, const char* name, int value);
 /* Sticky status bits of the context's kernels, read back from the device (THIS call synchronises with the device; the
  * others never do) and cleared.  Every device-side wait in this library is bounded; a wait that runs into its bound sets a bit
  * here and SKIPS its work instead of hanging the GPU.  Bit 1: the peer exchange (kurbm_peer_*) gave up waiting for a rank's flag.
- * Bit 2: the grid barrier of kurbm_cd_step_small timed out -- its grid was not resident (a CU mask, a device shared with a kernel
- * that never ends).  0 in every run this build has seen; the host classes read it at the end of every fit() and raise. */
+ * Bit 2: a barrier of kurbm_cd_step_small timed out -- its grid was not resident (a CU mask, a device shared with a kernel
+ * that never ends).  Bit 3: kurbm_cd_step_small found a workgroup on another XCD than kurbm_ctx_create had probed.  0 in every
+ * run this build has seen; the host classes read it at the end of every fit() and raise. */
 int kurbm_ctx_status(kurbm_ctx* ctx, int* bits);
 
 /* ---- RNG test hook: out[r, c] = u(row0 + r, c) under the contract above -------- */
@@ -402,8 +403,11 @@ int kurbm_cd_step_bf16_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* 
  * arguments, workspace (kurbm_workspace_bytes) and Philox counters as kurbm_cd_step; CD-1 from the data only (opts->k = 1,
  * no v_chain), applied in place (opts->apply = 1, no delta_out; `which` honoured).  Results agree with kurbm_cd_step to fp32
  * rounding (another summation order), not bit for bit.  The grid must be resident (at most one workgroup per CU, an otherwise
- * idle device); a barrier that times out sets bit 2 of kurbm_ctx_status and the update is skipped.  kurbm_cd_epoch_small: every
- * batch of an epoch in one call (returns the number of steps). */
+ * idle device); a barrier that times out sets bit 2 of kurbm_ctx_status and the update is skipped.  Where the context's probe
+ * found workgroup i of a grid on the XCD of workgroup i % 8 (MI355X in SPX mode), phases 1-3 of a 16-row band of the batch run
+ * inside ONE XCD and hand their planes over through its L2 (KURBM_SMALL_LOCAL, default 1; the launch is then always the whole
+ * device); a workgroup that finds itself on another XCD than probed sets bit 3.  kurbm_cd_epoch_small: every batch of an epoch
+ * in one call (returns the number of steps). */
 int kurbm_cd_step_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, int rows, int ldv,
                         const kurbm_cd_opts* opts, int which, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
 int kurbm_cd_epoch_small(kurbm_ctx* ctx, const kurbm_params* p, const float* V, int n_rows, int ldv, int batch_size,

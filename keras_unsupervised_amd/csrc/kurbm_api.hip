@@ -20,7 +20,7 @@ using namespace kurbm;
 // the launch path); kurbm_ctx_set_option changes one on a live context (tests and tuning sweeps).  KN_AUTO = "let the
 // planner decide".
 enum { KN_LDPAD, KN_X3_F8POS, KN_X3_BYTES, KN_X3_STATS_TALL, KN_BF16_SPLIT, KN_X3_FULL, KN_X3_TALL, KN_X3_MFAST, KN_X3_STATS_MFAST,
-       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_DP_CHUNKS, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_PAIR, KN_X3_SPLIT_STATS, KN_X3_ATR,
+       KN_UNFUSED_MIRROR, KN_X3_XCD2D, KN_REDUCE_TR, KN_DP_CHUNKS, KN_X3_STATS_BYTES, KN_MAP_SLOW, KN_X3_PAIR, KN_X3_SPLIT_STATS, KN_X3_ATR, KN_SMALL_LOCAL,
        KN_COUNT };
 constexpr int KN_AUTO = -1;
 static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
@@ -47,6 +47,8 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
                                    //    negative half on byte planes (Bernoulli visibles) or on the paired walk (Gaussian visibles)
     {"KURBM_X3_ATR", 1},           // 0: Gaussian visibles leave the h -> v half step as pieces in BOTH orientations; 1: row-major only, and the
                                    //    negative statistics read them through transposed LDS reads (with KURBM_X3_SPLIT_STATS)
+    {"KURBM_SMALL_LOCAL", 1},      // 1: the one-launch small step hands h_pos / v_neg between the workgroups of ONE XCD through its L2 (kurbm_small.hip;
+                                   //    where the context's probe found workgroup i on the XCD of workgroup i % 8), 0: every phase over the whole grid
 };
 
 constexpr size_t STATUS_BYTES = 4096;
@@ -58,6 +60,8 @@ struct kurbm_ctx {
     int force_split;    // KURBM_SPLIT
     int tile_major;     // KURBM_TILE_MAJOR (default 1): k-slices of a statistics tile share an XCD
     int knob[KN_COUNT];
+    int xcc_round_robin;      // 1: workgroup i of a grid runs on the XCD of workgroup i % 8 (probed at creation)
+    unsigned xcc_map;         // the XCD of workgroups g, g + 8, ... in nibble g
     unsigned* status;   // device word, sticky: kurbm_ctx_status, in front of the only device memory the library owns (STATUS_BYTES: behind
                         // the status word the grid barrier of kurbm_cd_step_small -- words 64 .. 223: eight per-XCD arrival counters, the
                         // grid's counter, the generation word, one 64-byte line each)
@@ -308,6 +312,25 @@ int kurbm_ctx_create(int device, kurbm_ctx** out) {
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->status), STATUS_BYTES);
         if (e == hipSuccess) e = hipMemset(c->status, 0, STATUS_BYTES);
+        // where do the workgroups of a grid run?  (the XCD-local schedule of the one-launch small step stands on the answer)
+        c->xcc_round_robin = 0; c->xcc_map = 0;
+        if (e == hipSuccess && c->ncu >= 8 && c->ncu <= 1024) {
+            unsigned* probe = nullptr;
+            unsigned host[1024];
+            if (hipMalloc(reinterpret_cast<void**>(&probe), sizeof(unsigned) * c->ncu) == hipSuccess) {
+                if (launch_xcc_probe(probe, c->ncu, nullptr) == hipSuccess &&
+                    hipMemcpy(host, probe, sizeof(unsigned) * c->ncu, hipMemcpyDeviceToHost) == hipSuccess) {
+                    bool rr = true;
+                    for (int b = 8; b < c->ncu; ++b) rr = rr && host[b] == host[b & 7];
+                    if (rr) {
+                        c->xcc_round_robin = 1;
+                        for (int g = 0; g < 8; ++g) c->xcc_map |= (host[g] & 15u) << (4 * g);
+                    }
+                }
+                (void)hipFree(probe);
+            }
+            (void)hipGetLastError();
+        }
         (void)hipSetDevice(prev);
         if (e != hipSuccess) {
             if (c->status) (void)hipFree(c->status);
@@ -523,6 +546,10 @@ int kurbm_cd_step_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_ba
     if (stat > nblk) nblk = stat;
     if (nblk > ctx->ncu) nblk = ctx->ncu;
     if (nblk > 1024) nblk = 1024;
+    // the XCD-local schedule: every XCD's workgroups own the row tiles tm = its number (mod 8), so the whole grid is launched
+    a.local = (ctx->knob[KN_SMALL_LOCAL] != 0 && ctx->xcc_round_robin && ctx->ncu <= 256) ? 1 : 0;   // (a group's barrier: 32 words)
+    a.xcc_map = ctx->xcc_map;
+    if (a.local) nblk = ctx->ncu;
     HIP_TRY(launch_cd1_small(a, nblk, static_cast<hipStream_t>(stream)));
     return KURBM_OK;
 }

@@ -74,19 +74,65 @@ __device__ bool grid_barrier(const SmallArgs& a, unsigned& gen) {
     return ok != 0;
 }
 
-// plane accessors: agent scope (see grid_barrier)
-__device__ __forceinline__ float ld_plane(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_plane(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// ... 16 bytes at once: a buffer load with the sc1 bit (agent scope), `base` wave-uniform
-typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 ld_plane4(const float* base, unsigned byte_off) {
-    const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xFFFFFFFF, 0x00020000);
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d, (int)byte_off, 0, 16));
+// The workgroups of ONE XCD (group g = blockIdx.x % 8, up to 32 of them) have arrived: the barrier between the phases of the
+// `local` schedule.  No atomics (they execute at the memory side): every workgroup owns ONE word of its group's 128-byte line,
+// stores the barrier's number there (plain: through the L1 into the XCD's L2) and wave 0 polls the whole line with non-temporal
+// loads, a lane per workgroup, until every word has reached that number -- one L2 round trip to arrive, one per poll (0.24 us
+// each: xcd_l2_probe) where the grid's barrier pays three memory-side ones.  A wave has drained its plane stores before it
+// arrives.  The numbers only grow (signed differences); a timeout reports through the status word like the grid barrier's.
+__device__ bool group_barrier(const SmallArgs& a, unsigned target) {
+    __shared__ int gok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int g = blockIdx.x & 7, rank = blockIdx.x >> 3, n = ((int)gridDim.x - g + 7) >> 3;
+        const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(a.bar + 160 + 32 * g, 0, 0xFFFFFFFF, 0x00020000);
+        if (threadIdx.x == 0) __builtin_amdgcn_raw_buffer_store_b32(target, d, 4 * rank, 0, 0);
+        const int lane = threadIdx.x;
+        const unsigned long long t0 = realtime_ticks();
+        bool ok = true;
+        for (;;) {
+            const unsigned f = lane < n ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(d, 4 * lane, 0, 2) : target;
+            if (__all((int)(f - target) >= 0)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (realtime_ticks() - t0 > a.timeout_ticks) { ok = false; break; }
+        }
+        if (threadIdx.x == 0) gok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return gok != 0;
 }
 
-__device__ __forceinline__ void st_plane4(float* base, unsigned byte_off, f32x4 v) {
-    const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFF, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, v), d, (int)byte_off, 0, 16);
+// plane accessors.  SC = 1: agent scope (see grid_barrier) -- past this CU's L1 and this XCD's L2.  SC = 2: the scope of ONE XCD:
+// a plain store (the L1 is write-through: the data is in the XCD's L2 once the store has drained) and a NON-TEMPORAL load, which
+// is served by that L2 past the L1 -- for planes whose writer and readers all run on one XCD (the `local` schedule below) and
+// which are never read any other way, so that no L1 ever holds a line of them.  tools/probes/xcd_l2_probe.hip measured the ways a
+// word gets from one CU of an XCD to another: nt load 0.24 us behind the store, scalar load after s_dcache_inv 0.24, sc1 store +
+// sc1 load 0.64; a plain load, an sc0 load (workgroup scope hits the L1 unless the kernel runs in threadgroup-split mode) and a
+// load behind `buffer_inv sc0` never see it, and neither does an atomic (it executes at the memory side, behind the dirty L2
+// line).  SC = 0: plain.
+typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
+template <int SC> struct ScopeAux { static constexpr int aux = SC == 1 ? 16 : (SC == 2 ? 2 : 0); };   // sc1 / nt
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFF, 0x00020000);
+}
+// (`base` wave-uniform, the element index per lane: a buffer access takes its descriptor from scalar registers)
+template <int SC> __device__ __forceinline__ float ld_plane(const float* base, unsigned idx) {
+    if constexpr (SC == 0) return base[idx];
+    else if constexpr (SC == 1) return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane_rsrc(base), (int)(4u * idx), 0, ScopeAux<2>::aux));
+}
+template <int SC> __device__ __forceinline__ void st_plane(float* base, unsigned idx, float v) {
+    if constexpr (SC == 1) __hip_atomic_store(base + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), plane_rsrc(base), (int)(4u * idx), 0, 0);
+}
+// ... 16 bytes at once: buffer accesses, `base` wave-uniform
+template <int SC> __device__ __forceinline__ f32x4 ld_plane4(const float* base, unsigned byte_off) {
+    if constexpr (SC == 0) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+    else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc(base), (int)byte_off, 0, ScopeAux<SC>::aux));
+}
+__device__ __forceinline__ void st_plane4(float* base, unsigned byte_off, f32x4 v) {   // (agent scope)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, v), plane_rsrc(base), (int)byte_off, 0, ScopeAux<1>::aux);
 }
 
 // One 16 x 16 tile of C = A . B over the k chunks [c0, c1) of 16 (stride cs): the lane (x = lane & 15, slot = lane >> 4) feeds
@@ -95,8 +141,8 @@ __device__ __forceinline__ void st_plane4(float* base, unsigned byte_off, f32x4 
 //   KS (k strided):               four 4-byte loads per chunk     X[k][x]  = base[k * ld + x]
 // x_ok / k < K guard ragged shapes (zeros contribute nothing).  NEG: the A values enter negated.
 // A and B point at the TILE (KC: its first row; KS: its first column), so x = lane & 15 indexes both.
-// A_PL / B_PL: the operand is a plane another workgroup wrote in an earlier phase -- agent-scope dword loads.
-template <bool A_KC, bool B_KC, bool NEG, bool A_PL = false, bool B_PL = false>
+// A_PL / B_PL: the operand is a plane another workgroup wrote in an earlier phase -- loads of scope 1 (agent) or 2 (its XCD).
+template <bool A_KC, bool B_KC, bool NEG, int A_PL = 0, int B_PL = 0>
 __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A, int lda, bool a_ok, const float* __restrict__ B, int ldb, bool b_ok,
                                          int K, int c0, int c1, int cs, int x, int slot) {
     // UN chunks at a time: ALL their loads are issued before the first MFMA -- the operands come from L2 with a few waves per CU, so
@@ -113,27 +159,27 @@ __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A
             const bool live = c < c1;
             if (A_KC) {
                 if (live && a_ok && k + 3 < K) {
-                    const f32x4 t = A_PL ? ld_plane4(A, 4u * (unsigned)(x * lda + k)) : *reinterpret_cast<const f32x4*>(A + (size_t)x * lda + k);
+                    const f32x4 t = ld_plane4<A_PL>(A, 4u * (unsigned)(x * lda + k));
                     av[u][0] = t.x; av[u][1] = t.y; av[u][2] = t.z; av[u][3] = t.w;
                 }
                 else
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) av[u][e] = (live && a_ok && k + e < K) ? (A_PL ? ld_plane(A + (size_t)x * lda + k + e) : A[(size_t)x * lda + k + e]) : 0.f;
+                    for (int e = 0; e < 4; ++e) av[u][e] = (live && a_ok && k + e < K) ? ld_plane<A_PL>(A, (unsigned)(x * lda + k + e)) : 0.f;
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) av[u][e] = (live && a_ok && k + e < K) ? (A_PL ? ld_plane(A + (size_t)(k + e) * lda + x) : A[(size_t)(k + e) * lda + x]) : 0.f;
+                for (int e = 0; e < 4; ++e) av[u][e] = (live && a_ok && k + e < K) ? ld_plane<A_PL>(A, (unsigned)((k + e) * lda + x)) : 0.f;
             }
             if (B_KC) {
                 if (live && b_ok && k + 3 < K) {
-                    const f32x4 t = B_PL ? ld_plane4(B, 4u * (unsigned)(x * ldb + k)) : *reinterpret_cast<const f32x4*>(B + (size_t)x * ldb + k);
+                    const f32x4 t = ld_plane4<B_PL>(B, 4u * (unsigned)(x * ldb + k));
                     bv[u][0] = t.x; bv[u][1] = t.y; bv[u][2] = t.z; bv[u][3] = t.w;
                 }
                 else
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[u][e] = (live && b_ok && k + e < K) ? (B_PL ? ld_plane(B + (size_t)x * ldb + k + e) : B[(size_t)x * ldb + k + e]) : 0.f;
+                    for (int e = 0; e < 4; ++e) bv[u][e] = (live && b_ok && k + e < K) ? ld_plane<B_PL>(B, (unsigned)(x * ldb + k + e)) : 0.f;
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bv[u][e] = (live && b_ok && k + e < K) ? (B_PL ? ld_plane(B + (size_t)(k + e) * ldb + x) : B[(size_t)(k + e) * ldb + x]) : 0.f;
+                for (int e = 0; e < 4; ++e) bv[u][e] = (live && b_ok && k + e < K) ? ld_plane<B_PL>(B, (unsigned)((k + e) * ldb + x)) : 0.f;
             }
         }
 #pragma unroll
@@ -143,31 +189,46 @@ __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A
     }
 }
 
-// A half step over all 16 x 16 tiles of out [rows][N]: a workgroup takes tiles blockIdx.x, + gridDim.x, ...; its eight waves
-// split the k chunks and meet in LDS (added in wave order); wave 0 finishes the tile: bias, activation, draw, store -- row-major
-// into `out` (nullable) and transposed into outT [N][ldt] (rows of the tile past the batch as zeros: phase 4 reads whole chunks).
+// A half step over all 16 x 16 tiles of out [rows][N].  A workgroup takes one tile per pass and its eight waves split the k
+// chunks -- or TWO neighbouring tiles per pass, four waves each, where that saves a pass (h -> v: 49 column tiles of a short k) --
+// and meet in LDS (added in wave order); the first wave of a tile finishes it: bias, activation, draw, store -- row-major into
+// `out` (nullable) and transposed into outT [N][ldt] (rows of the tile past the batch as zeros: phase 4 reads whole chunks).
 // HV = false: out = f(in . W + b_h) (k = visible units, W read as [k][n]); HV = true: out = f(in . W^T + b_v) (W read as [n][k]).
 constexpr int SMALL_WAVES = 8;
-template <bool HV, bool IN_PL>
-__device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in, int ld_in, float* __restrict__ out, int ldo,
+// IN_PL / OUT_SC: the scope of the input plane's loads and of the row-major output's stores (0 plain, 1 agent, 2 one XCD).
+// LOCAL: row tile tm belongs to the workgroups of XCD tm % 8 (workgroup i runs on XCD i % 8: k_cd1_small checks it), which then
+// exchange the row-major planes of phases 1-3 through their own L2 and meet at a barrier of their own.
+template <bool HV, int IN_PL, int OUT_SC, bool LOCAL, bool TWO>
+__device__ __forceinline__ void half_step_tiles(const SmallArgs& a, const float* __restrict__ in, int ld_in, float* __restrict__ out, int ldo,
                                 float* __restrict__ outT, int act, int noise, const RngArgs& rng, float* red) {
     const int K = HV ? a.n_hid : a.n_vis, N = HV ? a.n_vis : a.n_hid;
     const float* bias = HV ? a.b_v : a.b_h;
     const int tiles_m = (a.rows + 15) / 16, tiles_n = (N + 15) / 16, nch = (K + 15) / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, slot = lane >> 4;
-    for (int t = blockIdx.x; t < tiles_m * tiles_n; t += gridDim.x) {
-        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const int grp = blockIdx.x & 7, rank = blockIdx.x >> 3, ngrp = ((int)gridDim.x - grp + 7) >> 3;
+    // slots: the tiles (pairs of tiles) this workgroup's passes cover -- LOCAL: slot q = rank, rank + ngrp, ... of every row tile
+    // tm = grp, grp + 8, ...; else q = blockIdx.x, + gridDim.x, ... of the whole list
+    const int units = LOCAL ? tiles_n : tiles_m * tiles_n, cap = LOCAL ? ngrp : (int)gridDim.x;
+    constexpr int per = TWO ? 2 : 1, kw = TWO ? 4 : SMALL_WAVES;
+    const int sub = TWO ? (wave >> 2) : 0, wsub = TWO ? (wave & 3) : wave;
+    const int nslots = (units + per - 1) / per;
+    for (int tm0 = LOCAL ? grp : 0; tm0 < (LOCAL ? tiles_m : 1); tm0 += 8)
+    for (int q = LOCAL ? rank : (int)blockIdx.x; q < nslots; q += cap) {
+        const int u = q * per + sub;                       // this wave's tile among the units
+        const bool live = !TWO || u < units;
+        const int tm = LOCAL ? tm0 : u / tiles_n, tn = LOCAL ? u : u - tm * tiles_n;
         const int m = tm * 16 + x, n = tn * 16 + x;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* At = in + (size_t)tm * 16 * ld_in;                                      // rows of the batch, k contiguous
-        if (HV) tile_mma<true, true, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + (size_t)tn * 16 * a.ldw, a.ldw, n < N, K, wave, nch, SMALL_WAVES, x, slot);   // W^T: rows = visible units
-        else    tile_mma<true, false, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + tn * 16, a.ldw, n < N, K, wave, nch, SMALL_WAVES, x, slot);                 // W as [k][n]
+        if (live) {
+            const float* At = in + (size_t)tm * 16 * ld_in;                                      // rows of the batch, k contiguous
+            if (HV) tile_mma<true, true, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + (size_t)tn * 16 * a.ldw, a.ldw, n < N, K, wsub, nch, kw, x, slot);   // W^T: rows = visible units
+            else    tile_mma<true, false, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + tn * 16, a.ldw, n < N, K, wsub, nch, kw, x, slot);                 // W as [k][n]
+        }
         *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc;
         __syncthreads();
-        if (wave == 0) {
-            f32x4 s = *reinterpret_cast<const f32x4*>(red + lane * 4);
-#pragma unroll
-            for (int q = 1; q < SMALL_WAVES; ++q) s += *reinterpret_cast<const f32x4*>(red + (q * 64 + lane) * 4);
+        if (wsub == 0 && live) {
+            f32x4 s = *reinterpret_cast<const f32x4*>(red + (wave * 64 + lane) * 4);
+            for (int w = 1; w < kw; ++w) s += *reinterpret_cast<const f32x4*>(red + ((wave + w) * 64 + lane) * 4);
             const int col = tn * 16 + x, row0 = tm * 16 + 4 * slot;     // C layout: lane holds rows row0 .. row0 + 3 of column col
             if (col < N) {
                 const float b = bias[col];
@@ -185,7 +246,7 @@ __device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in
                     if (noise == NOISE_BERNOULLI) y = (u32_to_unit(w1[r]) < p) ? 1.f : 0.f;
                     else if (noise == NOISE_GAUSSIAN) y = p + box_muller(u32_to_unit(w1[r]), u32_to_unit(w2[r]));
                     if (row0 + r < a.rows) {
-                        if (out) st_plane(out + (size_t)(row0 + r) * ldo + col, y);
+                        if (out) st_plane<OUT_SC>(out, (unsigned)((row0 + r) * ldo + col), y);
                         yt[r] = y;
                     }
                 }
@@ -196,6 +257,23 @@ __device__ void half_step_small(const SmallArgs& a, const float* __restrict__ in
     }
 }
 
+// (TWO tiles per pass where that saves a pass and k is short -- decided the same way by every workgroup of the grid)
+template <bool HV, int IN_PL, int OUT_SC, bool LOCAL>
+__device__ __forceinline__ void half_step_small(const SmallArgs& a, const float* __restrict__ in, int ld_in, float* __restrict__ out, int ldo,
+                                                float* __restrict__ outT, int act, int noise, const RngArgs& rng, float* red) {
+    if constexpr (HV) {
+        const int tiles_m = (a.rows + 15) / 16, tiles_n = (a.n_vis + 15) / 16, nch = (a.n_hid + 15) / 16;
+        const int grp = blockIdx.x & 7, ngrp = ((int)gridDim.x - grp + 7) >> 3;
+        const int units = LOCAL ? tiles_n : tiles_m * tiles_n, cap = LOCAL ? ngrp : (int)gridDim.x;
+        if (nch <= 32 && (units + 2 * cap - 1) / (2 * cap) < (units + cap - 1) / cap) {
+            half_step_tiles<HV, IN_PL, OUT_SC, LOCAL, true>(a, in, ld_in, out, ldo, outT, act, noise, rng, red);
+            return;
+        }
+    }
+    half_step_tiles<HV, IN_PL, OUT_SC, LOCAL, false>(a, in, ld_in, out, ldo, outT, act, noise, rng, red);
+}
+
+template <bool LOCAL>
 __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
     __shared__ __attribute__((aligned(16))) float red[SMALL_WAVES * 64 * 4];
     unsigned gen = 0;
@@ -209,21 +287,50 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
 #define KURBM_SST(i) do { } while (0)
 #endif
     KURBM_SST(0);
-    // 1: h_pos ~ p(h | v_pos)                                                   rbm.py:120
-    half_step_small<false, false>(a, a.v, a.ldv, a.h_pos, a.ldh, a.h_posT, act_h, NOISE_BERNOULLI, a.rng_h, red);
-    KURBM_SST(1);
-    ok = grid_barrier(a, gen) && ok;
-    KURBM_SST(2);
-    // 2: v_neg ~ p(v | h_pos)                                                   rbm.py:121-123 / :143-144
-    if (ok) half_step_small<true, true>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, a.v_negT, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red);
-    KURBM_SST(3);
-    ok = grid_barrier(a, gen) && ok;
-    KURBM_SST(4);
-    // 3: h_neg = sigmoid(v_neg . W + b_h): probabilities in both modes          rbm.py:124 / :145
-    if (ok) half_step_small<false, true>(a, a.v_neg, a.ldn, nullptr, 0, a.h_negT, ACT_SIGMOID, NOISE_NONE, a.rng_h, red);
-    KURBM_SST(5);
-    ok = grid_barrier(a, gen) && ok;
-    KURBM_SST(6);
+    if constexpr (LOCAL) {
+        // The `local` schedule: row tile tm of phases 1-3 belongs to the workgroups of XCD tm % 8, which hand h_pos and v_neg to
+        // each other through their L2 and meet at barriers of their own; only the transposed planes -- phase 4's operands, read by
+        // everybody -- leave at agent scope, and only phase 4 waits for the whole grid.
+        unsigned ggen = 0, xcc = 0;
+        if (threadIdx.x == 0) {
+            // this workgroup's own word: the number of the last barrier its group completed (every workgroup of a group holds the same)
+            const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(a.bar + 160 + 32 * (blockIdx.x & 7), 0, 0xFFFFFFFF, 0x00020000);
+            ggen = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(d, 4 * (int)(blockIdx.x >> 3), 0, 2);
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            // (the schedule stands on "workgroup i runs on XCD i % 8", as the context's probe found it: anything else is reported)
+            if ((xcc & 15u) != ((a.xcc_map >> (4 * (blockIdx.x & 7))) & 15u))
+                __hip_atomic_fetch_or(a.status, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ggen = __shfl(ggen, 0);            // (wave 0 polls with it; the other waves do not use it)
+        half_step_small<false, 0, 2, true>(a, a.v, a.ldv, a.h_pos, a.ldh, a.h_posT, act_h, NOISE_BERNOULLI, a.rng_h, red);
+        KURBM_SST(1);
+        ok = group_barrier(a, ggen + 1u) && ok;
+        KURBM_SST(2);
+        if (ok) half_step_small<true, 2, 2, true>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, a.v_negT, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red);
+        KURBM_SST(3);
+        ok = group_barrier(a, ggen + 2u) && ok;
+        KURBM_SST(4);
+        if (ok) half_step_small<false, 2, 2, true>(a, a.v_neg, a.ldn, nullptr, 0, a.h_negT, ACT_SIGMOID, NOISE_NONE, a.rng_h, red);
+        KURBM_SST(5);
+        ok = grid_barrier(a, gen) && ok;
+        KURBM_SST(6);
+    } else {
+        // 1: h_pos ~ p(h | v_pos)                                                   rbm.py:120
+        half_step_small<false, 0, 1, false>(a, a.v, a.ldv, a.h_pos, a.ldh, a.h_posT, act_h, NOISE_BERNOULLI, a.rng_h, red);
+        KURBM_SST(1);
+        ok = grid_barrier(a, gen) && ok;
+        KURBM_SST(2);
+        // 2: v_neg ~ p(v | h_pos)                                                   rbm.py:121-123 / :143-144
+        if (ok) half_step_small<true, 1, 1, false>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, a.v_negT, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red);
+        KURBM_SST(3);
+        ok = grid_barrier(a, gen) && ok;
+        KURBM_SST(4);
+        // 3: h_neg = sigmoid(v_neg . W + b_h): probabilities in both modes          rbm.py:124 / :145
+        if (ok) half_step_small<false, 1, 1, false>(a, a.v_neg, a.ldn, nullptr, 0, a.h_negT, ACT_SIGMOID, NOISE_NONE, a.rng_h, red);
+        KURBM_SST(5);
+        ok = grid_barrier(a, gen) && ok;
+        KURBM_SST(6);
+    }
     if (!ok) {
         if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -238,15 +345,18 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
             const int ti = task / tiles_h, tj = task - ti * tiles_h;
             const int i = ti * 16 + x, j = tj * 16 + x;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int col = tj * 16 + x, row0 = ti * 16 + 4 * slot;
+            float wv[4];                                   // the tile of W itself: requested first, needed last
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wv[r] = (col < a.n_hid && row0 + r < a.n_vis) ? a.W[(size_t)(row0 + r) * a.ldw + col] : 0.f;
             // dW = v_pos^T . h_pos - v_neg^T . h_neg   (rbm.py:125-126), k = the batch rows: contiguous in the transposed planes, strided
             // in the data.  (One batch of loads per product.  Both products' loads in ONE batch: 15.0 against 8.3 us for this phase.)
-            tile_mma<false, true, false, false, true>(acc, a.v + ti * 16, a.ldv, i < a.n_vis, a.h_posT + (size_t)tj * 16 * a.ldt, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
-            tile_mma<true, true, true, true, true>(acc, a.v_negT + (size_t)ti * 16 * a.ldt, a.ldt, i < a.n_vis, a.h_negT + (size_t)tj * 16 * a.ldt, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
-            const int col = tj * 16 + x, row0 = ti * 16 + 4 * slot;
+            tile_mma<false, true, false, 0, 1>(acc, a.v + ti * 16, a.ldv, i < a.n_vis, a.h_posT + (size_t)tj * 16 * a.ldt, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+            tile_mma<true, true, true, 1, 1>(acc, a.v_negT + (size_t)ti * 16 * a.ldt, a.ldt, i < a.n_vis, a.h_negT + (size_t)tj * 16 * a.ldt, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
             if (col < a.n_hid)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (row0 + r < a.n_vis) a.W[(size_t)(row0 + r) * a.ldw + col] += a.lr * acc[r];      // rbm.py:127-128
+                    if (row0 + r < a.n_vis) a.W[(size_t)(row0 + r) * a.ldw + col] = wv[r] + a.lr * acc[r];      // rbm.py:127-128
         } else {
             // a bias group: lane (column x, row group slot) adds rows 16 e + 4 slot .. + 3 of its column for e = 0, 1, ... (16-byte loads
             // from the transposed planes, whose rows past the batch are zeros; the data itself is row-major: dwords), then the four row
@@ -264,8 +374,8 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
                     for (int e = 0; e < 4; ++e) {
                         const int r = r0 + 16 * e;
                         const bool live = r < a.rows;
-                        nq[e] = live ? ld_plane4(negT, 4u * (unsigned)(col * a.ldt + r)) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (hid) pq[e] = live ? ld_plane4(posT, 4u * (unsigned)(col * a.ldt + r)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        nq[e] = live ? ld_plane4<1>(negT, 4u * (unsigned)(col * a.ldt + r)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (hid) pq[e] = live ? ld_plane4<1>(posT, 4u * (unsigned)(col * a.ldt + r)) : f32x4{0.f, 0.f, 0.f, 0.f};
                         else
 #pragma unroll
                             for (int q = 0; q < 4; ++q) pq[e][q] = (r + q < a.rows) ? a.v[(size_t)(r + q) * a.ldv + col] : 0.f;
@@ -286,8 +396,20 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
     KURBM_SST(7);
 }
 
+// which XCD does workgroup i of a grid run on?  (kurbm_ctx_create: the `local` schedule needs i -> i % 8, up to a renaming of XCDs)
+__global__ void k_xcc_probe(unsigned* out) {
+    unsigned xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc & 15u;
+}
+hipError_t launch_xcc_probe(unsigned* out, int nblk, hipStream_t st) {
+    hipLaunchKernelGGL(k_xcc_probe, dim3(nblk), dim3(64 * SMALL_WAVES), 0, st, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_cd1_small(const SmallArgs& a, int nblk, hipStream_t st) {
-    hipLaunchKernelGGL(k_cd1_small, dim3(nblk), dim3(64 * SMALL_WAVES), 0, st, a);
+    if (a.local) hipLaunchKernelGGL(k_cd1_small<true>, dim3(nblk), dim3(64 * SMALL_WAVES), 0, st, a);
+    else hipLaunchKernelGGL(k_cd1_small<false>, dim3(nblk), dim3(64 * SMALL_WAVES), 0, st, a);
     return hipGetLastError();
 }
 

@@ -219,14 +219,16 @@ class DeviceRBM:
         return 1 if v.bf16_exact else 3
 
     def check_status(self):
-        """Raise if a kernel of this context reported a problem (kurbm_ctx_status; synchronises with the device).  Both bits there
-        are mean a device-side wait ran into its bound and an update was SKIPPED -- training must not go on from that state: bit 1 =
-        the peer exchange (a rank never arrived), bit 2 = the grid barrier of the one-launch small step (its grid was not resident:
-        a CU mask, a device shared with another process)."""
+        """Raise if a kernel of this context reported a problem (kurbm_ctx_status; synchronises with the device).  Bits 1 and 2
+        mean a device-side wait ran into its bound and an update was SKIPPED -- training must not go on from that state: bit 1 =
+        the peer exchange (a rank never arrived), bit 2 = a barrier of the one-launch small step (its grid was not resident: a CU
+        mask, a device shared with another process); bit 3 = that step found a workgroup on another XCD than the context's probe
+        had (its XCD-local schedule may then have read a stale plane: KURBM_SMALL_LOCAL=0 takes the grid-wide schedule)."""
         bits = self.ctx.status()
         if bits:
             what = [name for bit, name in ((2, "the peer exchange timed out waiting for a rank"),
-                                           (4, "the one-launch small step found its grid not resident")) if bits & bit]
+                                           (4, "the one-launch small step found its grid not resident"),
+                                           (8, "the one-launch small step found a workgroup on an unexpected XCD")) if bits & bit]
             raise _lib.KurbmError("kurbm status %#x: %s; an update was skipped and the replicas / weights are no longer what the "
                                   "step sequence defines -- reload the weights (set_weights)" % (bits, "; ".join(what) or "unknown bit"))
 

@@ -243,11 +243,14 @@ def test_small_step_config1_golden(gpu_device, golden_dir):
 
 @pytest.mark.parametrize("cfg", [dict(B=64, nv=784, nh=256), dict(B=128, nv=784, nh=128), dict(B=16, nv=784, nh=128), dict(B=50, nv=70, nh=90),
                                  dict(B=37, nv=100, nh=33, gauss=True), dict(B=128, nv=784, nh=128, gauss=True), dict(B=200, nv=300, nh=520)])
-def test_small_step_vs_oracle(gpu_device, cfg):
+@pytest.mark.parametrize("local", [1, 0])
+def test_small_step_vs_oracle(gpu_device, ctx_option, cfg, local):
     """The one-launch step against the oracle's fused CD-1 step (same Philox counters: the draws are the oracle's), the parameters
     after TWO steps at the 1e-4 bar (the second step runs on the first one's weights and on the barrier state it left); ragged
     shapes, Gaussian visibles; `which` restricts the update as kurbm_cd_step's does; the epoch call is its step loop, bit for bit;
-    and the five-launch fp32 path gives the same parameters to fp32 rounding."""
+    and the five-launch fp32 path gives the same parameters to fp32 rounding.  Both schedules: phases 1-3 inside one XCD each
+    (KURBM_SMALL_LOCAL=1, the default) and over the whole grid."""
+    ctx_option("KURBM_SMALL_LOCAL", local, 1)
     B, nv, nh = cfg["B"], cfg["nv"], cfg["nh"]
     mode = O.MODE_VISIBLE_GAUSSIAN if cfg.get("gauss") else O.MODE_VISIBLE_BERNOULLI
     W, b_h, b_v = synthetic_params(nv, nh, seed=2600 + B)
@@ -284,6 +287,26 @@ def test_small_step_vs_oracle(gpu_device, cfg):
         for j, (a, b0, f) in enumerate(zip(ew.get_weights(), (W, b_h, b_v), full.get_weights())):
             assert np.array_equal(a, f if j == idx else b0), (which, j)
     e.check_status()
+
+
+@pytest.mark.parametrize("shape", [(128, 784, 128), (64, 784, 256), (40, 100, 72)])
+def test_small_step_local_schedule_is_deterministic(gpu_device, shape):
+    """600 one-launch steps (the XCD-local schedule: planes and barrier words handed over through an XCD's L2) twice from the same
+    weights: bit-identical parameters, finite, no status bit -- a stale read of a plane or of a barrier word would show here."""
+    B, nv, nh = shape
+    W, b_h, b_v = synthetic_params(nv, nh, seed=77)
+    v = synthetic_binary(8 * B, nv, seed=78, p=0.3)
+    vd = _dm(v, gpu_device)
+    runs = []
+    for _ in range(2):
+        e = _engine(W, b_h, b_v, gpu_device)
+        for step in range(600):
+            e.cd_step(vd, B, (step % 8) * B, 1e-2 / B, 5, step, compute="small")
+        e.check_status()
+        runs.append(e.get_weights())
+    for a, b in zip(*runs):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert np.max(np.abs(runs[0][0] - W)) > 1e-3      # (it did train)
 
 
 @pytest.mark.parametrize("cfg", [dict(B=50, nv=70, nh=90, k=1), dict(B=133, nv=200, nh=120, k=3),
