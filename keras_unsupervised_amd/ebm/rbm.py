@@ -307,6 +307,7 @@ class RBM(object):
         rank, world = dp.world()
         d = self._dev
         self.last_scores = []
+        self._data_real = self.compute_dtype == "auto" and d.v_pieces(Vd) != 1   # ('auto' asks once what the data is)
         if self.persistent and self._v_chain is None:
             # fantasy particles start at the first batch of the data
             self._v_chain = DeviceMatrix.zeros(bs, d.n_vis, d.device)
@@ -366,14 +367,24 @@ class RBM(object):
         return None
 
     def _compute(self):
+        """The compute path of this fit.  'auto' reads tools/small_crossover.py's tables (784 visible units, one MI355X;
+        profiles/r04_e_compute_path_crossover.txt):
+        * the one-launch step (CD-1 from the data, one GPU) up to batch 128 with up to 1024 hidden units and up to batch 256 with up
+          to 512 -- 30-57 us per step where the multi-launch paths take 55-110;
+        * 0/1 data in Bernoulli mode: x3 at every other size (it beats the fp32-MFMA launches from batch 64 on);
+        * real-valued data or Gaussian visibles (three pieces per value, seven launches): x3 from rows x n_vis x n_hid >= 6e8 on
+          (batch 1024 at 784 x 1024, 1536 at 784 x 512), the fp32-MFMA kernels below."""
         c = self.compute_dtype
+        small_ok = self.cd_k == 1 and not self.persistent and dp.world()[1] == 1
         if c == "auto":
-            c = "x3" if int(self.hps["batch_size"]) >= 256 else "small"
-        if c == "small" and (self.cd_k != 1 or self.persistent or dp.world()[1] > 1 or
-                             (self.compute_dtype == "auto" and (int(self.hps["batch_size"]) > 128 or self.output_dim > 256))):
-            # the one-launch step is CD-1 from the data on one GPU; 'auto' takes it where it wins (tools/small_times.py: up to
-            # batch 128 and 256 hidden units); everything else runs the five-launch path
-            c = "fp32"
+            b, h = int(self.hps["batch_size"]), int(self.output_dim)
+            if small_ok and ((b <= 128 and h <= 1024) or (b <= 256 and h <= 512)):
+                return "small"
+            real = self.mode == MODE_VISIBLE_GAUSSIAN or getattr(self, "_data_real", False)
+            n_vis = self._dev.n_vis if self._dev is not None else 784
+            return "x3" if (not real or float(b) * n_vis * h >= 6e8) else "fp32"
+        if c == "small" and not small_ok:
+            return "fp32"     # the one-launch step is CD-1 from the data on one GPU; everything else runs the five-launch path
         return c
 
     def _update_local(self, Vd, lo, rows, lr, step):

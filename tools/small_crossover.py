@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""python tools/small_crossover.py [binary|grey] [batch,batch,...]
+Where does the one-launch step stop winning, and where does x3 start to?  Microseconds per CD-1 step (HIP events, steps queued back to back) of the
+'small', 'fp32' (five launches) and 'x3' paths over a grid of batch sizes and hidden widths, 784 visible units -- the table
+RBM._compute()'s 'auto' rule is read from."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from keras_unsupervised_amd.ebm.engine import DeviceMatrix, DeviceRBM  # noqa: E402
+
+dev = torch.device("cuda", 0)
+g = np.random.default_rng(0)
+nv, steps = 784, 100
+grey = len(sys.argv) > 1 and sys.argv[1] == "grey"      # grey levels k / 255 in Gaussian-visible mode (the reference's default call)
+mode = 1 if grey else 0
+print("data %s, mode %s" % ("grey levels" if grey else "0/1", "gauss" if mode else "bern"))
+print("%-22s %8s %8s %8s" % ("784 x hidden, batch", "small", "fp32", "x3"))
+batches = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64, 128, 192, 256, 384, 512]
+for bs in batches:
+    V = DeviceMatrix.from_host((np.floor(g.random((bs * steps, nv)) * 256.0) / 255.0).astype(np.float32) if grey else
+                               (g.random((bs * steps, nv)) < 0.19).astype(np.float32), dev)
+    for nh in (128, 256, 512, 1024):
+        row = []
+        for compute in ("small", "fp32", "x3"):
+            if compute == "small" and bs > 512:
+                row.append(float("nan"))
+                continue
+            eng = DeviceRBM(g.uniform(-0.05, 0.05, (nv, nh)).astype(np.float32), np.zeros(nh, np.float32), np.zeros(nv, np.float32), dev)
+            planes = eng.make_planes(V, [(i * bs, bs) for i in range(steps)], mode) if compute == "x3" else None
+
+            def run(n):
+                if compute == "x3":
+                    for i in range(n):
+                        eng.cd_step(V, bs, i * bs, 1e-3 / bs, 1, i, mode=mode, compute="x3", planes=planes)
+                else:
+                    eng.cd_epoch(V, bs * n, bs, 1e-3 / bs, 1, 0, mode=mode, compute=compute)
+            run(10)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            run(steps)
+            b.record()
+            torch.cuda.synchronize()
+            eng.check_status()
+            row.append(a.elapsed_time(b) / steps * 1e3)
+        print("784 x %4d, batch %3d  %8.1f %8.1f %8.1f" % (nh, bs, *row), flush=True)
