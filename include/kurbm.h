@@ -120,8 +120,7 @@ int kurbm_ctx_set_option(kurbm_ctx* ctx, const char* name, int value);
  * others never do) and cleared.  Every device-side wait in this library is bounded; a wait that runs into its bound sets a bit
  * here and SKIPS its work instead of hanging the GPU.  Bit 1: the peer exchange (kurbm_peer_*) gave up waiting for a rank's flag.
  * Bit 2: a barrier of kurbm_cd_step_small timed out -- its grid was not resident (a CU mask, a device shared with a kernel
- * that never ends).  Bit 3: kurbm_cd_step_small found a workgroup on another XCD than kurbm_ctx_create had probed.  0 in every
- * run this build has seen; the host classes read it at the end of every fit() and raise. */
+ * that never ends).  0 in every run this build has seen; the host classes read it at the end of every fit() and raise. */
 int kurbm_ctx_status(kurbm_ctx* ctx, int* bits);
 
 /* ---- RNG test hook: out[r, c] = u(row0 + r, c) under the contract above -------- */
@@ -404,14 +403,29 @@ int kurbm_cd_step_bf16_dp(kurbm_ctx* ctx, kurbm_comm* comm, const kurbm_params* 
  * no v_chain), applied in place (opts->apply = 1, no delta_out; `which` honoured).  Results agree with kurbm_cd_step to fp32
  * rounding (another summation order), not bit for bit.  The grid must be resident (at most one workgroup per CU, an otherwise
  * idle device); a barrier that times out sets bit 2 of kurbm_ctx_status and the update is skipped.  Where the context's probe
- * found workgroup i of a grid on the XCD of workgroup i % 8 (MI355X in SPX mode), phases 1-3 of a 16-row band of the batch run
- * inside ONE XCD and hand their planes over through its L2 (KURBM_SMALL_LOCAL, default 1; the launch is then always the whole
- * device); a workgroup that finds itself on another XCD than probed sets bit 3.  kurbm_cd_epoch_small: every batch of an epoch
+ * found the dispatcher dealing consecutive workgroups to consecutive XCDs (MI355X in SPX mode), phases 1-3 of a 16-row band of
+ * the batch run inside ONE XCD -- the workgroups that find themselves on it -- and hand their planes over through its L2
+ * (KURBM_SMALL_LOCAL, default 1; the launch is then always the whole device).  kurbm_cd_epoch_small: every batch of an epoch
  * in one call (returns the number of steps). */
 int kurbm_cd_step_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, int rows, int ldv,
                         const kurbm_cd_opts* opts, int which, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
 int kurbm_cd_epoch_small(kurbm_ctx* ctx, const kurbm_params* p, const float* V, int n_rows, int ldv, int batch_size,
                          const kurbm_cd_opts* opts, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+/* ... and the per-step score of fit(verbose = 1), rbm.py:225-233, the same way: *score = mean |F(v) - F(v')| over the batch,
+ * v' a fresh one-step reconstruction (opts->chain, sites 0 and 1, opts->seed / row0 / step / mode), in ONE launch with nothing
+ * returned to the host; F (nullable, device [2 * rows]) receives F(v) then F(v').  At most 512 rows.  Workspace as for
+ * kurbm_cd_step (kurbm_workspace_bytes).  Replaces the reference's four graph executions of its score (two free energies,
+ * two sampling half steps). */
+int kurbm_score_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, int rows, int ldv, const kurbm_cd_opts* opts,
+                      float* score, float* F, void* workspace, size_t workspace_bytes, kurbm_stream_t stream);
+/* `score` is 8-byte aligned and receives TWO floats in one system-scope store: the score, then 1.0f -- so it may be pinned host
+ * memory that the caller polls for the second word instead of synchronising with the device.  kurbm_cd_epoch_small_scored is
+ * the batch loop of fit(verbose = 1) as one call: the update of every batch followed by its score (opts->step counts up for
+ * both; the score draws from chain `score_chain`), scores[2 i], scores[2 i + 1] = the score of step i and its 1.0f.  Returns the
+ * number of steps. */
+int kurbm_cd_epoch_small_scored(kurbm_ctx* ctx, const kurbm_params* p, const float* V, int n_rows, int ldv, int batch_size,
+                                const kurbm_cd_opts* opts, int score_chain, float* scores, void* workspace, size_t workspace_bytes,
+                                kurbm_stream_t stream);
 
 /* ---- data parallel, plan B: the exchange through peer pointers, no collective library ----------------------------
  *

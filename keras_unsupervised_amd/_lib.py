@@ -92,6 +92,8 @@ SIGNATURES = {
     "kurbm_cd_step_bf16_dp": (_i, [_vp, _vp, _PP, _vp, _sz, _vp, _i, _i, _OP, _i, _vp, _sz, _vp]),
     "kurbm_cd_step_small": (_i, [_vp, _PP, _vp, _i, _i, _OP, _i, _vp, _sz, _vp]),
     "kurbm_cd_epoch_small": (_i, [_vp, _PP, _vp, _i, _i, _i, _OP, _vp, _sz, _vp]),
+    "kurbm_score_small": (_i, [_vp, _PP, _vp, _i, _i, _OP, _vp, _vp, _vp, _sz, _vp]),
+    "kurbm_cd_epoch_small_scored": (_i, [_vp, _PP, _vp, _i, _i, _i, _OP, _i, _vp, _vp, _sz, _vp]),
     "kurbm_peer_handle_bytes": (_sz, []),
     "kurbm_peer_create": (_i, [_i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "kurbm_peer_handle": (_i, [_vp, _vp, _sz]),

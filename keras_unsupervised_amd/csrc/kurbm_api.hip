@@ -48,7 +48,7 @@ static const struct { const char* env; int dflt; } KNOBS[KN_COUNT] = {
     {"KURBM_X3_ATR", 1},           // 0: Gaussian visibles leave the h -> v half step as pieces in BOTH orientations; 1: row-major only, and the
                                    //    negative statistics read them through transposed LDS reads (with KURBM_X3_SPLIT_STATS)
     {"KURBM_SMALL_LOCAL", 1},      // 1: the one-launch small step hands h_pos / v_neg between the workgroups of ONE XCD through its L2 (kurbm_small.hip;
-                                   //    where the context's probe found workgroup i on the XCD of workgroup i % 8), 0: every phase over the whole grid
+                                   //    where the context's probe found the dispatcher dealing consecutive workgroups to consecutive XCDs), 0: every phase over the whole grid
 };
 
 constexpr size_t STATUS_BYTES = 4096;
@@ -60,8 +60,8 @@ struct kurbm_ctx {
     int force_split;    // KURBM_SPLIT
     int tile_major;     // KURBM_TILE_MAJOR (default 1): k-slices of a statistics tile share an XCD
     int knob[KN_COUNT];
-    int xcc_round_robin;      // 1: workgroup i of a grid runs on the XCD of workgroup i % 8 (probed at creation)
-    unsigned xcc_map;         // the XCD of workgroups g, g + 8, ... in nibble g
+    int xcc_round_robin;      // 1: a whole-device grid puts one workgroup of every octet (b / 8) on each of eight XCDs (probed at creation)
+    unsigned xcc_map;         // the XCDs of workgroups 0 .. 7 of the probe launch, a nibble each (diagnostic)
     unsigned* status;   // device word, sticky: kurbm_ctx_status, in front of the only device memory the library owns (STATUS_BYTES: behind
                         // the status word the grid barrier of kurbm_cd_step_small -- words 64 .. 223: eight per-XCD arrival counters, the
                         // grid's counter, the generation word, one 64-byte line each)
@@ -320,8 +320,16 @@ int kurbm_ctx_create(int device, kurbm_ctx** out) {
             if (hipMalloc(reinterpret_cast<void**>(&probe), sizeof(unsigned) * c->ncu) == hipSuccess) {
                 if (launch_xcc_probe(probe, c->ncu, nullptr) == hipSuccess &&
                     hipMemcpy(host, probe, sizeof(unsigned) * c->ncu, hipMemcpyDeviceToHost) == hipSuccess) {
-                    bool rr = true;
-                    for (int b = 8; b < c->ncu; ++b) rr = rr && host[b] == host[b & 7];
+                    // the model the schedule stands on: eight XCDs, and on each of them exactly one workgroup of every octet
+                    // (workgroup b: octet b / 8) -- consecutive workgroups go to consecutive XCDs, from wherever the dispatcher stood
+                    bool rr = (c->ncu % 8) == 0;
+                    unsigned seen[8][32];
+                    memset(seen, 0, sizeof seen);
+                    for (int b = 0; rr && b < c->ncu; ++b) {
+                        const unsigned x = host[b];
+                        if (x > 7u || (seen[x][(b >> 3) >> 5] >> ((b >> 3) & 31)) & 1u) rr = false;
+                        else seen[x][(b >> 3) >> 5] |= 1u << ((b >> 3) & 31);
+                    }
                     if (rr) {
                         c->xcc_round_robin = 1;
                         for (int g = 0; g < 8; ++g) c->xcc_map |= (host[g] & 15u) << (4 * g);
@@ -552,6 +560,64 @@ int kurbm_cd_step_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_ba
     if (a.local) nblk = ctx->ncu;
     HIP_TRY(launch_cd1_small(a, nblk, static_cast<hipStream_t>(stream)));
     return KURBM_OK;
+}
+
+// The per-step score of fit(verbose = 1) for a small RBM in ONE launch (kurbm_small.hip: k_score_small).
+int kurbm_score_small(kurbm_ctx* ctx, const kurbm_params* p, const float* v_batch, int rows, int ldv, const kurbm_cd_opts* o,
+                      float* score, float* F, void* workspace, size_t workspace_bytes, kurbm_stream_t stream) {
+    if (!ctx || !o || !score) return fail(KURBM_ERR_ARG, "null argument");
+    if (reinterpret_cast<uintptr_t>(score) & 7) return fail(KURBM_ERR_ARG, "score must be 8-byte aligned (two floats are written)");
+    if (int e = check_params(p)) return e;
+    if (rows <= 0 || rows > SMALL_ROWS_MAX) return fail(KURBM_ERR_ARG, "rows must be in [1, %d]", SMALL_ROWS_MAX);
+    if (bad_matrix(v_batch, ldv, p->n_vis)) return fail(KURBM_ERR_ARG, "v_batch: null, misaligned, ld %% 4 != 0 or ld < n_vis");
+    if (o->mode != KURBM_MODE_VISIBLE_BERNOULLI && o->mode != KURBM_MODE_VISIBLE_GAUSSIAN) return fail(KURBM_ERR_ARG, "unknown mode %d", o->mode);
+    if (o->row0 & 3) return fail(KURBM_ERR_ARG, "row0 must be a multiple of 4");
+    if (!workspace || !aligned16(workspace)) return fail(KURBM_ERR_ARG, "workspace is null or misaligned");
+    const Workspace w = carve(ctx, workspace, rows, p->n_vis, p->n_hid, 1);
+    if (w.bytes > workspace_bytes) return fail(KURBM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    SmallArgs a;
+    memset(&a, 0, sizeof a);
+    a.W = p->W; a.b_h = p->b_h; a.b_v = p->b_v; a.n_vis = p->n_vis; a.n_hid = p->n_hid; a.ldw = p->ldw;
+    a.v = v_batch; a.rows = rows; a.ldv = ldv;
+    a.h_pos = w.h_pos; a.h_neg = w.h_neg; a.v_neg = w.v_neg; a.ldh = w.ldh; a.ldn = w.ldv;
+    a.ldt = round_up(rows, 16);
+    a.h_posT = w.small_t;                    // (the row partials live in the transposed planes' space)
+    a.bar = ctx->status + 64; a.status = ctx->status;
+    a.timeout_ticks = 200000000ull;
+    const uint32_t base = o->chain * 64u;
+    a.rng_h = make_rng(o->seed, o->row0, base + 0u, o->step);
+    a.rng_v = make_rng(o->seed, o->row0, base + 1u, o->step);
+    a.gauss = (o->mode == KURBM_MODE_VISIBLE_GAUSSIAN) ? 1 : 0;
+    a.score = score; a.F = F;
+    const int tm = ceil_div(rows, 16), tv = ceil_div(p->n_vis, 16), th = ceil_div(p->n_hid, 16);
+    int nblk = tm * th > tm * tv ? tm * th : tm * tv;
+    if (nblk > ctx->ncu) nblk = ctx->ncu;
+    a.local = (ctx->knob[KN_SMALL_LOCAL] != 0 && ctx->xcc_round_robin && ctx->ncu <= 256) ? 1 : 0;
+    a.xcc_map = ctx->xcc_map;
+    if (a.local) nblk = ctx->ncu;
+    HIP_TRY(launch_score_small(a, nblk, static_cast<hipStream_t>(stream)));
+    return KURBM_OK;
+}
+
+// An epoch of fit(verbose = 1) for a small RBM in one call: every batch's update followed by its score (rbm.py:211-234), two
+// launches per step, nothing read back -- scores[2 * step] receives the score and scores[2 * step + 1] a 1.0f when it has landed
+// (device memory, or pinned host memory that the caller polls while the device runs on).  Returns the number of steps.
+int kurbm_cd_epoch_small_scored(kurbm_ctx* ctx, const kurbm_params* p, const float* V, int n_rows, int ldv, int batch_size,
+                                const kurbm_cd_opts* opts, int score_chain, float* scores, void* workspace, size_t workspace_bytes,
+                                kurbm_stream_t stream) {
+    if (!ctx || !opts || !scores) return fail(KURBM_ERR_ARG, "null argument");
+    if (n_rows < 0 || batch_size <= 0) return fail(KURBM_ERR_ARG, "bad row count / batch size");
+    kurbm_cd_opts o = *opts, so = *opts;
+    so.chain = score_chain;
+    int steps = 0;
+    for (int lo = 0; lo < n_rows; lo += batch_size, ++steps) {
+        const int rows = (n_rows - lo < batch_size) ? n_rows - lo : batch_size;
+        if (int e = kurbm_cd_step_small(ctx, p, V + (size_t)lo * ldv, rows, ldv, &o, 7, workspace, workspace_bytes, stream)) return e;
+        if (int e = kurbm_score_small(ctx, p, V + (size_t)lo * ldv, rows, ldv, &so, scores + 2 * (size_t)steps, nullptr, workspace,
+                                      workspace_bytes, stream)) return e;
+        ++o.step; ++so.step;
+    }
+    return steps;
 }
 
 int kurbm_cd_epoch_small(kurbm_ctx* ctx, const kurbm_params* p, const float* V, int n_rows, int ldv, int batch_size,

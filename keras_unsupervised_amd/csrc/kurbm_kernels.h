@@ -348,11 +348,13 @@ struct SmallArgs {
     int n_vis, n_hid, ldw, rows, ldv, ldh, ldn, ldt;
     int which, gauss;
     float lr;
+    float* score; float* F;    // k_score_small: the mean |F(v) - F(v')| (device float) and, nullable, F(v) then F(v') [2 rows]
     int local;                 // 1: the XCD-local schedule of phases 1-3 (kurbm_small.hip)
     unsigned xcc_map;          // ... and the XCD of group g (workgroups g, g + 8, ...) in nibble g, as the context's probe found it
 };
 hipError_t launch_cd1_small(const SmallArgs& a, int nblk, hipStream_t st);
 hipError_t launch_xcc_probe(unsigned* out, int nblk, hipStream_t st);
+hipError_t launch_score_small(const SmallArgs& a, int nblk, hipStream_t st);
 }
 // kurbm_peer.hip <-> kurbm_api.hip
 struct kurbm_ctx;

@@ -74,18 +74,30 @@ __device__ bool grid_barrier(const SmallArgs& a, unsigned& gen) {
     return ok != 0;
 }
 
-// The workgroups of ONE XCD (group g = blockIdx.x % 8, up to 32 of them) have arrived: the barrier between the phases of the
+// The XCD this workgroup runs on (XCC_ID, wave-uniform).  The `local` schedule groups workgroups by it -- NOT by blockIdx.x % 8: the
+// dispatcher deals workgroups to the XCDs in turn, but a grid starts where the one before it stopped (found when the tests ran
+// in another order: status bit 3 of the first version).  Within a group a workgroup's rank is blockIdx.x / 8: consecutive
+// workgroups go to consecutive XCDs, so the eight of one octet land on eight different XCDs whatever the starting point, and each
+// XCD gets every rank once; if a launch ever broke that, a rank would be missing in some group and its barrier would time out
+// (status bit 2) -- never a silent wrong answer.
+__device__ __forceinline__ int xcc_of_workgroup() {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return (int)(xcc & 7u);
+}
+
+// The workgroups of ONE XCD (group g = its XCC_ID, up to 32 of them) have arrived: the barrier between the phases of the
 // `local` schedule.  No atomics (they execute at the memory side): every workgroup owns ONE word of its group's 128-byte line,
 // stores the barrier's number there (plain: through the L1 into the XCD's L2) and wave 0 polls the whole line with non-temporal
 // loads, a lane per workgroup, until every word has reached that number -- one L2 round trip to arrive, one per poll (0.24 us
 // each: xcd_l2_probe) where the grid's barrier pays three memory-side ones.  A wave has drained its plane stores before it
 // arrives.  The numbers only grow (signed differences); a timeout reports through the status word like the grid barrier's.
-__device__ bool group_barrier(const SmallArgs& a, unsigned target) {
+__device__ bool group_barrier(const SmallArgs& a, int g, unsigned target) {
     __shared__ int gok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x < 64) {
-        const int g = blockIdx.x & 7, rank = blockIdx.x >> 3, n = ((int)gridDim.x - g + 7) >> 3;
+        const int rank = blockIdx.x >> 3, n = (int)gridDim.x >> 3;
         const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(a.bar + 160 + 32 * g, 0, 0xFFFFFFFF, 0x00020000);
         if (threadIdx.x == 0) __builtin_amdgcn_raw_buffer_store_b32(target, d, 4 * rank, 0, 0);
         const int lane = threadIdx.x;
@@ -196,16 +208,19 @@ __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A
 // HV = false: out = f(in . W + b_h) (k = visible units, W read as [k][n]); HV = true: out = f(in . W^T + b_v) (W read as [n][k]).
 constexpr int SMALL_WAVES = 8;
 // IN_PL / OUT_SC: the scope of the input plane's loads and of the row-major output's stores (0 plain, 1 agent, 2 one XCD).
-// LOCAL: row tile tm belongs to the workgroups of XCD tm % 8 (workgroup i runs on XCD i % 8: k_cd1_small checks it), which then
+// LOCAL: row tile tm belongs to the workgroups of XCD tm % 8 (`grp` = the XCD this workgroup runs on: xcc_of_workgroup), which then
 // exchange the row-major planes of phases 1-3 through their own L2 and meet at a barrier of their own.
-template <bool HV, int IN_PL, int OUT_SC, bool LOCAL, bool TWO>
+// RP (the score's phases): the finishing wave also leaves a partial row sum of its tile -- over the tile's 16 columns, by DPP adds --
+// in rowpart[tn][row] at agent scope: RP = 1 softplus of the pre-activations (the hidden term of a free energy, rbm.py:73-75),
+// RP = 2 the outputs times this site's bias (v' . b_v, its visible term).
+template <bool HV, int IN_PL, int OUT_SC, bool LOCAL, bool TWO, int RP = 0>
 __device__ __forceinline__ void half_step_tiles(const SmallArgs& a, const float* __restrict__ in, int ld_in, float* __restrict__ out, int ldo,
-                                float* __restrict__ outT, int act, int noise, const RngArgs& rng, float* red) {
+                                float* __restrict__ outT, int act, int noise, const RngArgs& rng, float* red, float* __restrict__ rowpart = nullptr, int grp = 0) {
     const int K = HV ? a.n_hid : a.n_vis, N = HV ? a.n_vis : a.n_hid;
     const float* bias = HV ? a.b_v : a.b_h;
     const int tiles_m = (a.rows + 15) / 16, tiles_n = (N + 15) / 16, nch = (K + 15) / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, slot = lane >> 4;
-    const int grp = blockIdx.x & 7, rank = blockIdx.x >> 3, ngrp = ((int)gridDim.x - grp + 7) >> 3;
+    const int rank = blockIdx.x >> 3, ngrp = (int)gridDim.x >> 3;   // (LOCAL: the grid is a whole number of octets)
     // slots: the tiles (pairs of tiles) this workgroup's passes cover -- LOCAL: slot q = rank, rank + ngrp, ... of every row tile
     // tm = grp, grp + 8, ...; else q = blockIdx.x, + gridDim.x, ... of the whole list
     const int units = LOCAL ? tiles_n : tiles_m * tiles_n, cap = LOCAL ? ngrp : (int)gridDim.x;
@@ -230,6 +245,7 @@ __device__ __forceinline__ void half_step_tiles(const SmallArgs& a, const float*
             f32x4 s = *reinterpret_cast<const f32x4*>(red + (wave * 64 + lane) * 4);
             for (int w = 1; w < kw; ++w) s += *reinterpret_cast<const f32x4*>(red + ((wave + w) * 64 + lane) * 4);
             const int col = tn * 16 + x, row0 = tm * 16 + 4 * slot;     // C layout: lane holds rows row0 .. row0 + 3 of column col
+            f32x4 rp = {0.f, 0.f, 0.f, 0.f};
             if (col < N) {
                 const float b = bias[col];
                 uint32_t w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
@@ -248,9 +264,16 @@ __device__ __forceinline__ void half_step_tiles(const SmallArgs& a, const float*
                     if (row0 + r < a.rows) {
                         if (out) st_plane<OUT_SC>(out, (unsigned)((row0 + r) * ldo + col), y);
                         yt[r] = y;
+                        if (RP == 1) rp[r] = softplusf(xv);
+                        if (RP == 2) rp[r] = y * b;
                     }
                 }
                 if (outT) st_plane4(outT, 4u * (unsigned)(col * a.ldt + row0), yt);
+            }
+            if constexpr (RP != 0) {   // (every lane of the wave: the sums run over the 16 lanes of a row group)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rp[r] = row16_sum(rp[r]);
+                if (x == 0) st_plane4(rowpart, 4u * (unsigned)(tn * a.ldt + row0), rp);
             }
         }
         __syncthreads();
@@ -258,19 +281,20 @@ __device__ __forceinline__ void half_step_tiles(const SmallArgs& a, const float*
 }
 
 // (TWO tiles per pass where that saves a pass and k is short -- decided the same way by every workgroup of the grid)
-template <bool HV, int IN_PL, int OUT_SC, bool LOCAL>
+template <bool HV, int IN_PL, int OUT_SC, bool LOCAL, int RP = 0>
 __device__ __forceinline__ void half_step_small(const SmallArgs& a, const float* __restrict__ in, int ld_in, float* __restrict__ out, int ldo,
-                                                float* __restrict__ outT, int act, int noise, const RngArgs& rng, float* red) {
+                                                float* __restrict__ outT, int act, int noise, const RngArgs& rng, float* red,
+                                                float* __restrict__ rowpart = nullptr, int grp = 0) {
     if constexpr (HV) {
         const int tiles_m = (a.rows + 15) / 16, tiles_n = (a.n_vis + 15) / 16, nch = (a.n_hid + 15) / 16;
-        const int grp = blockIdx.x & 7, ngrp = ((int)gridDim.x - grp + 7) >> 3;
+        const int ngrp = (int)gridDim.x >> 3;
         const int units = LOCAL ? tiles_n : tiles_m * tiles_n, cap = LOCAL ? ngrp : (int)gridDim.x;
         if (nch <= 32 && (units + 2 * cap - 1) / (2 * cap) < (units + cap - 1) / cap) {
-            half_step_tiles<HV, IN_PL, OUT_SC, LOCAL, true>(a, in, ld_in, out, ldo, outT, act, noise, rng, red);
+            half_step_tiles<HV, IN_PL, OUT_SC, LOCAL, true, RP>(a, in, ld_in, out, ldo, outT, act, noise, rng, red, rowpart, grp);
             return;
         }
     }
-    half_step_tiles<HV, IN_PL, OUT_SC, LOCAL, false>(a, in, ld_in, out, ldo, outT, act, noise, rng, red);
+    half_step_tiles<HV, IN_PL, OUT_SC, LOCAL, false, RP>(a, in, ld_in, out, ldo, outT, act, noise, rng, red, rowpart, grp);
 }
 
 template <bool LOCAL>
@@ -291,26 +315,23 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
         // The `local` schedule: row tile tm of phases 1-3 belongs to the workgroups of XCD tm % 8, which hand h_pos and v_neg to
         // each other through their L2 and meet at barriers of their own; only the transposed planes -- phase 4's operands, read by
         // everybody -- leave at agent scope, and only phase 4 waits for the whole grid.
-        unsigned ggen = 0, xcc = 0;
+        const int grp = xcc_of_workgroup();
+        unsigned ggen = 0;
         if (threadIdx.x == 0) {
-            // this workgroup's own word: the number of the last barrier its group completed (every workgroup of a group holds the same)
-            const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(a.bar + 160 + 32 * (blockIdx.x & 7), 0, 0xFFFFFFFF, 0x00020000);
+            // this workgroup's own word: the number of the last barrier its group completed (every word of a group holds the same)
+            const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(a.bar + 160 + 32 * grp, 0, 0xFFFFFFFF, 0x00020000);
             ggen = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(d, 4 * (int)(blockIdx.x >> 3), 0, 2);
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            // (the schedule stands on "workgroup i runs on XCD i % 8", as the context's probe found it: anything else is reported)
-            if ((xcc & 15u) != ((a.xcc_map >> (4 * (blockIdx.x & 7))) & 15u))
-                __hip_atomic_fetch_or(a.status, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         ggen = __shfl(ggen, 0);            // (wave 0 polls with it; the other waves do not use it)
-        half_step_small<false, 0, 2, true>(a, a.v, a.ldv, a.h_pos, a.ldh, a.h_posT, act_h, NOISE_BERNOULLI, a.rng_h, red);
+        half_step_small<false, 0, 2, true>(a, a.v, a.ldv, a.h_pos, a.ldh, a.h_posT, act_h, NOISE_BERNOULLI, a.rng_h, red, nullptr, grp);
         KURBM_SST(1);
-        ok = group_barrier(a, ggen + 1u) && ok;
+        ok = group_barrier(a, grp, ggen + 1u) && ok;
         KURBM_SST(2);
-        if (ok) half_step_small<true, 2, 2, true>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, a.v_negT, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red);
+        if (ok) half_step_small<true, 2, 2, true>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, a.v_negT, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red, nullptr, grp);
         KURBM_SST(3);
-        ok = group_barrier(a, ggen + 2u) && ok;
+        ok = group_barrier(a, grp, ggen + 2u) && ok;
         KURBM_SST(4);
-        if (ok) half_step_small<false, 2, 2, true>(a, a.v_neg, a.ldn, nullptr, 0, a.h_negT, ACT_SIGMOID, NOISE_NONE, a.rng_h, red);
+        if (ok) half_step_small<false, 2, 2, true>(a, a.v_neg, a.ldn, nullptr, 0, a.h_negT, ACT_SIGMOID, NOISE_NONE, a.rng_h, red, nullptr, grp);
         KURBM_SST(5);
         ok = grid_barrier(a, gen) && ok;
         KURBM_SST(6);
@@ -394,6 +415,117 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
         }
     }
     KURBM_SST(7);
+}
+
+// ------------------------------------------------------------------------------------
+// The per-step score of fit(verbose = 1), rbm.py:225-233, of a small RBM in ONE launch: mean_r |F(v_r) - F(v'_r)| with v' a fresh
+// one-step reconstruction (sites rng_h, rng_v of the score's chain).  Three phases on the schedules of k_cd1_small --
+//   1  h = sample of the hidden site from v          + the softplus row partials of v   (F's hidden term)
+//   2  v' = sample of the visible site from h        + the row partials of v' . b_v
+//   3  (v' . W + b_h: nothing stored)                + the softplus row partials of v'
+// -- and no grid-wide barrier: a workgroup that is done counts itself in, and the LAST one adds the partials up (fixed order),
+// takes the mean and leaves.  v . b_v of the data is computed beside phase 1 by a workgroup with nothing else to do there.
+// Row partials: rp1 [tiles_h][ldt], rpv [tiles_v][ldt], rp2 [tiles_h][ldt], vb [ldt] in the workspace (agent scope).
+template <bool LOCAL>
+__global__ __launch_bounds__(64 * SMALL_WAVES) void k_score_small(SmallArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[SMALL_WAVES * 64 * 4];
+    __shared__ int last;
+    const int act_h = a.gauss ? ACT_RELU : ACT_SIGMOID, act_v = a.gauss ? ACT_LINEAR : ACT_SIGMOID;
+    const int tiles_h = (a.n_hid + 15) / 16, tiles_v = (a.n_vis + 15) / 16, tiles_m = (a.rows + 15) / 16;
+    float* rp1 = a.h_posT;                              // (the transposed planes' space: nothing of a step is alive here)
+    float* rpv = rp1 + (size_t)tiles_h * a.ldt;
+    float* rp2 = rpv + (size_t)tiles_v * a.ldt;
+    float* vb = rp2 + (size_t)tiles_h * a.ldt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // v . b_v of the data, a wave per row: LOCAL -- the last workgroup of every XCD's group, for the rows of that group's row tiles
+    // (it has no tile in phase 1: at most 16 column tiles there); else the grid's last workgroup, every row
+    auto data_dot = [&](int r) {
+        float t = 0.f;
+        for (int c = lane; c < a.n_vis; c += 64) t += a.v[(size_t)r * a.ldv + c] * a.b_v[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) st_plane<1>(vb, (unsigned)r, t);
+    };
+    bool ok = true;
+    if constexpr (LOCAL) {
+        unsigned ggen = 0;
+        const int grp = xcc_of_workgroup(), rank = blockIdx.x >> 3, ngrp = (int)gridDim.x >> 3;
+        if (threadIdx.x == 0) {
+            const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc(a.bar + 160 + 32 * grp, 0, 0xFFFFFFFF, 0x00020000);
+            ggen = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(d, 4 * rank, 0, 2);
+        }
+        ggen = __shfl(ggen, 0);
+        half_step_small<false, 0, 2, true, 1>(a, a.v, a.ldv, a.h_pos, a.ldh, nullptr, act_h, NOISE_BERNOULLI, a.rng_h, red, rp1, grp);
+        if (rank == ngrp - 1)
+            for (int tm = grp; tm < tiles_m; tm += 8)
+                for (int r = tm * 16 + wave; r < tm * 16 + 16 && r < a.rows; r += SMALL_WAVES) data_dot(r);
+        ok = group_barrier(a, grp, ggen + 1u) && ok;
+        if (ok) half_step_small<true, 2, 2, true, 2>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, nullptr, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red, rpv, grp);
+        ok = group_barrier(a, grp, ggen + 2u) && ok;
+        if (ok) half_step_small<false, 2, 2, true, 1>(a, a.v_neg, a.ldn, nullptr, 0, nullptr, ACT_LINEAR, NOISE_NONE, a.rng_h, red, rp2, grp);
+    } else {
+        unsigned gen = 0;
+        if (threadIdx.x == 0) gen = __hip_atomic_load(a.bar + 16 * 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gen = __builtin_amdgcn_readfirstlane(gen);
+        half_step_small<false, 0, 1, false, 1>(a, a.v, a.ldv, a.h_pos, a.ldh, nullptr, act_h, NOISE_BERNOULLI, a.rng_h, red, rp1);
+        if (blockIdx.x == gridDim.x - 1)
+            for (int r = wave; r < a.rows; r += SMALL_WAVES) data_dot(r);
+        ok = grid_barrier(a, gen) && ok;
+        if (ok) half_step_small<true, 1, 1, false, 2>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, nullptr, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red, rpv);
+        ok = grid_barrier(a, gen) && ok;
+        if (ok) half_step_small<false, 1, 1, false, 1>(a, a.v_neg, a.ldn, nullptr, 0, nullptr, ACT_LINEAR, NOISE_NONE, a.rng_h, red, rp2);
+    }
+    if (!ok && threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // count this workgroup in (its partials have drained); the last one finishes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* cnt = a.bar + 448;
+        const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = prev == gridDim.x - 1u;
+        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last) return;
+    // |F(v) - F(v')| of every row (a thread per row: the partials of a row tile lie side by side), then a fixed-order tree
+    float* sums = red;                                  // 512 floats of the 2048
+    float d = 0.f;
+    // (sixteen partials requested at a time: one at a time this loop was 65 memory-side round trips in a row, ~40 us)
+    auto column_sum = [&](const float* part, int ntile, int r, float acc) {
+        for (int t0 = 0; t0 < ntile; t0 += 16) {
+            float q[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) q[i] = t0 + i < ntile ? ld_plane<1>(part, (unsigned)((t0 + i) * a.ldt + r)) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc += q[i];
+        }
+        return acc;
+    };
+    for (int r = threadIdx.x; r < a.rows; r += 64 * SMALL_WAVES) {
+        const float f = column_sum(rp1, tiles_h, r, ld_plane<1>(vb, (unsigned)r));
+        const float f1 = column_sum(rp2, tiles_h, r, column_sum(rpv, tiles_v, r, 0.f));
+        if (a.F) { a.F[r] = -f; a.F[a.rows + r] = -f1; }
+        d += fabsf(f1 - f);                             // |(-f) - (-f1)|
+    }
+    sums[threadIdx.x] = d;
+    __syncthreads();
+    for (int w = 32 * SMALL_WAVES; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sums[threadIdx.x] += sums[threadIdx.x + w];
+        __syncthreads();
+    }
+    // the score and a 1.0f behind it as ONE 8-byte store at system scope: `score` may be pinned host memory, which the host
+    // polls for that second word instead of synchronising with the device (kurbm_cd_epoch_small_scored)
+    if (threadIdx.x == 0) {
+        const float sc = ok ? sums[0] / (float)a.rows : __builtin_nanf("");
+        const unsigned long long both = (unsigned long long)__float_as_uint(sc) | ((unsigned long long)__float_as_uint(1.0f) << 32);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.score), both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_score_small(const SmallArgs& a, int nblk, hipStream_t st) {
+    if (a.local) hipLaunchKernelGGL(k_score_small<true>, dim3(nblk), dim3(64 * SMALL_WAVES), 0, st, a);
+    else hipLaunchKernelGGL(k_score_small<false>, dim3(nblk), dim3(64 * SMALL_WAVES), 0, st, a);
+    return hipGetLastError();
 }
 
 // which XCD does workgroup i of a grid run on?  (kurbm_ctx_create: the `local` schedule needs i -> i % 8, up to a renaming of XCDs)

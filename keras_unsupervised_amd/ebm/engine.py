@@ -221,14 +221,13 @@ class DeviceRBM:
     def check_status(self):
         """Raise if a kernel of this context reported a problem (kurbm_ctx_status; synchronises with the device).  Bits 1 and 2
         mean a device-side wait ran into its bound and an update was SKIPPED -- training must not go on from that state: bit 1 =
-        the peer exchange (a rank never arrived), bit 2 = a barrier of the one-launch small step (its grid was not resident: a CU
-        mask, a device shared with another process); bit 3 = that step found a workgroup on another XCD than the context's probe
-        had (its XCD-local schedule may then have read a stale plane: KURBM_SMALL_LOCAL=0 takes the grid-wide schedule)."""
+        the peer exchange (a rank never arrived), bit 2 = a barrier of the one-launch small step or score (its grid was not
+        resident: a CU mask, a device shared with another process -- or the dispatcher did not deal its workgroups to the XCDs
+        in turn: KURBM_SMALL_LOCAL=0 takes the grid-wide schedule)."""
         bits = self.ctx.status()
         if bits:
             what = [name for bit, name in ((2, "the peer exchange timed out waiting for a rank"),
-                                           (4, "the one-launch small step found its grid not resident"),
-                                           (8, "the one-launch small step found a workgroup on an unexpected XCD")) if bits & bit]
+                                           (4, "the one-launch small step found its grid not resident")) if bits & bit]
             raise _lib.KurbmError("kurbm status %#x: %s; an update was skipped and the replicas / weights are no longer what the "
                                   "step sequence defines -- reload the weights (set_weights)" % (bits, "; ".join(what) or "unknown bit"))
 
@@ -455,6 +454,24 @@ class DeviceRBM:
         self._chain_written(v_chain, mode)
         return n
 
+    def cd_epoch_small_scored(self, v, n_rows, batch_size, lr, seed, step0, mode, score_chain, row_start=0):
+        """The batch loop of fit(verbose=1) for a small RBM as ONE library call (kurbm_cd_epoch_small_scored): every batch's
+        one-launch update followed by its one-launch score.  Returns (#steps, scores): scores is a PINNED host tensor
+        [steps, 2] that the device fills as it goes -- scores[i, 0] the score of step i, scores[i, 1] turning 1.0 when it has
+        landed -- so the caller prints the lines while the device runs on, without synchronising."""
+        steps = -(-int(n_rows) // int(batch_size)) if n_rows > 0 else 0
+        scores = torch.zeros((max(steps, 1), 2), dtype=torch.float32, pin_memory=True)
+        with torch.cuda.device(self.device):
+            ws = self.workspace(min(batch_size, max(n_rows, 1)))
+            opts = CdOpts(1, int(mode), float(lr), 1, None, None, int(seed), 0, int(step0) & 0xFFFFFFFF, 0)
+            n = self.lib.kurbm_cd_epoch_small_scored(self.ctx.handle, C.byref(self.params), v.ptr(row_start), int(n_rows), v.ld,
+                                                     int(batch_size), C.byref(opts), int(score_chain), scores.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), self._stream())
+            if n < 0:
+                check(n)
+        self._weights_written()
+        return n, scores
+
     def half_step_bf16(self, direction, x, rows, act, noise, seed, stream_id, step, row0=0, pieces=1, row_start=0,
                        want_prob=True, want_u=True):
         """One half step with bf16 products (pieces=3: the exact split, used by transform() on the x3 path; pieces=1:
@@ -528,6 +545,19 @@ class DeviceRBM:
                                           int(rows), v.ld, C.byref(opts), out.data_ptr(), None, ws.data_ptr(), ws.numel(),
                                           self._stream()))
         return out
+
+    def score_small(self, v, rows, row_start, seed, step, mode, chain, want_F=False):
+        """The same score for a small RBM in ONE launch (kurbm_score_small: csrc/kurbm_small.hip; at most 512 rows); returns a
+        device tensor whose element 0 is the score (want_F: and a [2, rows] tensor of F(v), F(v'))."""
+        with torch.cuda.device(self.device):
+            ws = self.workspace(rows)
+            opts = CdOpts(1, int(mode), 0.0, 0, None, None, int(seed), 0, int(step) & 0xFFFFFFFF, int(chain))
+            out = torch.empty(4, dtype=torch.float32, device=self.device)
+            F = torch.empty((2, rows), dtype=torch.float32, device=self.device) if want_F else None
+            check(self.lib.kurbm_score_small(self.ctx.handle, C.byref(self.params), v.ptr(row_start), int(rows), v.ld, C.byref(opts),
+                                             out.data_ptr(), F.data_ptr() if want_F else None, ws.data_ptr(), ws.numel(),
+                                             self._stream()))
+        return (out, F) if want_F else out
 
     def dump_plane(self, which, v, rows, mode=MODE_VISIBLE_BERNOULLI):
         """Test hook: one of the planes the last complete x3 CD-1 step on `rows` rows of v left in the workspace, as fp32

@@ -19,6 +19,7 @@ feeds all three updates; ``'reference_sequential'`` replays the reference's thre
 initialised, ``verbose=0`` to skip the score passes.
 """
 import collections
+import time
 
 import numpy as np
 import torch
@@ -278,6 +279,9 @@ class RBM(object):
         if self._large(rows):
             # one library call on the x3 kernels: same draws (chain CHAIN_SCORE, sites 0 and 1), products on the bf16 pieces
             return d.score_x3(Vd, rows, lo, self.seed, step, self.mode, CHAIN_SCORE, planes=self._planes)
+        if self._compute() == "small" and rows <= 512:
+            # small RBMs: the whole score in one launch, as their step is (same draws)
+            return d.score_small(Vd, rows, lo, self.seed, step, self.mode, CHAIN_SCORE)
         act_h, noise_h = hidden_site(self.mode)
         act_v, noise_v = visible_site(self.mode)
         fe = d.free_energy(Vd, rows, lo)
@@ -336,6 +340,8 @@ class RBM(object):
         # quiet single-GPU fused training (fp32 MFMA or x3): the whole batch loop of an epoch is one library call
         whole_epochs = (verbose != 1 and world == 1 and self.update_mode == "fused"
                         and self._compute() in ("fp32", "x3", "small"))
+        # ... and with the per-step score (the reference's default), for the one-launch small path
+        scored_epochs = (verbose == 1 and world == 1 and self.update_mode == "fused" and self._compute() == "small" and bs <= 512)
         def print_score(score, label):
             self.last_scores.append(score)
             print("\n{0:d}/{1:d}, score: {2:f}".format(label[0], label[1], score))   # rbm.py:234
@@ -347,6 +353,23 @@ class RBM(object):
                 self._update_count += d.cd_epoch(Vd, n, bs, lr, self.seed, self._update_count, k=self.cd_k,
                                                  mode=self.mode, v_chain=self._v_chain if self.persistent else None,
                                                  compute=self._compute(), planes=planes)
+                continue
+            if scored_epochs:
+                # small RBMs with the reference's default verbose = 1: the epoch's updates AND scores are queued by one library
+                # call (two launches per step); the scores land in pinned host memory, and the lines are printed, in order, as they do
+                steps, scores = d.cd_epoch_small_scored(Vd, n, bs, lr, self.seed, self._update_count, self.mode, CHAIN_SCORE)
+                self._update_count += steps
+                flags = scores.numpy()
+                for i in range(steps):
+                    spins = 0
+                    while flags[i, 1] != 1.0:
+                        spins += 1
+                        if spins > 2000:
+                            time.sleep(50e-6)
+                        if spins > 400000:     # (~20 s: the device never wrote it -- a skipped launch; the status word says why)
+                            d.check_status()
+                            raise _lib.KurbmError("the score of step %d never arrived" % (i + 1))
+                    print_score(float(flags[i, 0]), (i + 1, num_step))
                 continue
             for i in range(num_step):                                            # rbm.py:163
                 lo, hi = i * bs, min((i + 1) * bs, n)                            # rbm.py:211 / :218

@@ -292,7 +292,8 @@ def test_small_step_vs_oracle(gpu_device, ctx_option, cfg, local):
 @pytest.mark.parametrize("shape", [(128, 784, 128), (64, 784, 256), (40, 100, 72)])
 def test_small_step_local_schedule_is_deterministic(gpu_device, shape):
     """600 one-launch steps (the XCD-local schedule: planes and barrier words handed over through an XCD's L2) twice from the same
-    weights: bit-identical parameters, finite, no status bit -- a stale read of a plane or of a barrier word would show here."""
+    weights, other kernels of odd grid sizes in between (a launch starts on the XCD where the last one stopped): bit-identical
+    parameters, finite, no status bit -- a stale read of a plane or of a barrier word would show here."""
     B, nv, nh = shape
     W, b_h, b_v = synthetic_params(nv, nh, seed=77)
     v = synthetic_binary(8 * B, nv, seed=78, p=0.3)
@@ -301,6 +302,8 @@ def test_small_step_local_schedule_is_deterministic(gpu_device, shape):
     for _ in range(2):
         e = _engine(W, b_h, b_v, gpu_device)
         for step in range(600):
+            if step % 37 == 0:      # other grids in between: the next launch starts on whichever XCD the dispatcher stands at
+                junk = torch.empty(1000 * (1 + step % 7) + 13, device=gpu_device).fill_(1.0)
             e.cd_step(vd, B, (step % 8) * B, 1e-2 / B, 5, step, compute="small")
         e.check_status()
         runs.append(e.get_weights())
@@ -1556,3 +1559,39 @@ def test_score_one_call_vs_oracle(gpu_device, cfg):
     assert rel_err(Fh[:B], O.free_energy(V, W, b_h, b_v)) <= TOL
     assert abs(float(np.mean(np.abs(Fh[:B].astype(np.float64) - Fh[B:].astype(np.float64)))) - got) <= 1e-5 * max(1.0, abs(got))
     assert float(out[0].item()) == got
+
+
+@pytest.mark.parametrize("local", [1, 0])
+@pytest.mark.parametrize("cfg", [dict(B=128, nv=784, nh=128), dict(B=64, nv=784, nh=256, gauss=True), dict(B=128, nv=784, nh=128, real=True, gauss=True),
+                                 dict(B=37, nv=100, nh=33), dict(B=200, nv=300, nh=520, gauss=True), dict(B=16, nv=784, nh=1024)])
+def test_small_score_vs_oracle(gpu_device, ctx_option, cfg, local):
+    """kurbm_score_small -- the score of fit(verbose=1) for a small RBM in ONE launch (csrc/kurbm_small.hip: k_score_small), both
+    schedules -- against the oracle's step_score with the same counters, the free energies against O.free_energy, twice the same
+    bits, and against the five-call form the host class used before (free energy, two half steps, free energy)."""
+    from keras_unsupervised_amd.ebm.engine import CHAIN_SCORE
+    ctx_option("KURBM_SMALL_LOCAL", local, 1)
+    B, nv, nh = cfg["B"], cfg["nv"], cfg["nh"]
+    mode = O.MODE_VISIBLE_GAUSSIAN if cfg.get("gauss") else O.MODE_VISIBLE_BERNOULLI
+    W, b_h, b_v = synthetic_params(nv, nh, seed=2700 + B)
+    V = synthetic_real(B, nv, seed=2701 + B) if cfg.get("real") else synthetic_binary(B, nv, seed=2701 + B, p=0.3)
+    e = _engine(W, b_h, b_v, gpu_device)
+    vd = _dm(V, gpu_device)
+    s, F = e.score_small(vd, B, 0, 7, 3, mode, CHAIN_SCORE, want_F=True)
+    s2 = e.score_small(vd, B, 0, 7, 3, mode, CHAIN_SCORE)
+    torch.cuda.synchronize()
+    e.check_status()
+    got = float(s[0].item())
+    assert np.isfinite(got) and got == float(s2[0].item())
+    want = O.step_score(W, b_h, b_v, V, 7, 3, mode)
+    assert abs(got - want) <= 1e-3 * max(1.0, abs(want)), (got, want)
+    Fh = F.cpu().numpy()
+    assert rel_err(Fh[0], O.free_energy(V, W, b_h, b_v)) <= TOL
+    assert abs(float(np.mean(np.abs(Fh[0].astype(np.float64) - Fh[1].astype(np.float64)))) - got) <= 1e-5 * max(1.0, abs(got))
+    # a training step in between leaves the barrier state the next score starts from
+    e.cd_step(vd, B, 0, 1e-3, 9, 0, mode=mode, compute="small")
+    s3 = e.score_small(vd, B, 0, 7, 4, mode, CHAIN_SCORE)
+    torch.cuda.synchronize()
+    e.check_status()
+    Wn, bhn, bvn = e.get_weights()
+    want3 = O.step_score(Wn, bhn, bvn, V, 7, 4, mode)
+    assert abs(float(s3[0].item()) - want3) <= 1e-3 * max(1.0, abs(want3))

@@ -1,0 +1,18 @@
+import sys, time, io, contextlib
+import numpy as np, torch
+sys.path.insert(0, "/root/repo")
+from keras_unsupervised_amd.ebm import RBM
+g = np.random.default_rng(0)
+V = (np.floor(g.random((128 * 300, 784)) * 256.0) / 255.0).astype(np.float32)
+Vd = torch.from_numpy(V).cuda()
+for mode in (1, 0):
+    for verbose in (0, 1):
+        rbm = RBM({"batch_size": 128, "epochs": 1, "lr": 1e-3 / 128}, 128, mode=mode)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rbm.fit(Vd[: 128 * 8], verbose=verbose)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rbm.fit(Vd, verbose=verbose)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print("784 x 128, batch 128, mode %s, verbose=%d: %.1f us/step (compute %s)" % ("gauss" if mode else "bern", verbose, dt / 300 * 1e6, rbm._compute()))
