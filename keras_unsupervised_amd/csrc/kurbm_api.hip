@@ -216,7 +216,8 @@ static Workspace carve(const kurbm_ctx* ctx, void* base, int rows, int n_vis, in
     w.part_h = take((size_t)w.max_row_tiles * w.ld_part_h);
     w.part_v = take((size_t)w.max_row_tiles * w.ld_part_v);
     w.slab = take(w.slab_stride * pl.nsplit_bound);
-    w.small_t = rows <= SMALL_ROWS_MAX ? take((size_t)(2 * n_hid + n_vis) * round_up(rows, 16)) : nullptr;
+    // (the one-launch score keeps its row partials there: 2 ceil(n_hid / 16) + ceil(n_vis / 16) + 1 rows -- the + 4 covers one-unit layers)
+    w.small_t = rows <= SMALL_ROWS_MAX ? take((size_t)(2 * n_hid + n_vis + 4) * round_up(rows, 16)) : nullptr;
     (void)k;
     // free energy: row partials [col tiles][round_up(rows,4)] alias the front of the workspace
     const size_t fe = align_up((size_t)ceil_div(n_hid, 64) * round_up(rows, 4) * 4);

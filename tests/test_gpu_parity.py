@@ -242,7 +242,7 @@ def test_small_step_config1_golden(gpu_device, golden_dir):
 
 
 @pytest.mark.parametrize("cfg", [dict(B=64, nv=784, nh=256), dict(B=128, nv=784, nh=128), dict(B=16, nv=784, nh=128), dict(B=50, nv=70, nh=90),
-                                 dict(B=37, nv=100, nh=33, gauss=True), dict(B=128, nv=784, nh=128, gauss=True), dict(B=200, nv=300, nh=520)])
+                                 dict(B=37, nv=100, nh=33, gauss=True), dict(B=128, nv=784, nh=128, gauss=True), dict(B=200, nv=300, nh=520), dict(B=5, nv=3, nh=2)])
 @pytest.mark.parametrize("local", [1, 0])
 def test_small_step_vs_oracle(gpu_device, ctx_option, cfg, local):
     """The one-launch step against the oracle's fused CD-1 step (same Philox counters: the draws are the oracle's), the parameters
@@ -1563,7 +1563,7 @@ def test_score_one_call_vs_oracle(gpu_device, cfg):
 
 @pytest.mark.parametrize("local", [1, 0])
 @pytest.mark.parametrize("cfg", [dict(B=128, nv=784, nh=128), dict(B=64, nv=784, nh=256, gauss=True), dict(B=128, nv=784, nh=128, real=True, gauss=True),
-                                 dict(B=37, nv=100, nh=33), dict(B=200, nv=300, nh=520, gauss=True), dict(B=16, nv=784, nh=1024)])
+                                 dict(B=37, nv=100, nh=33), dict(B=200, nv=300, nh=520, gauss=True), dict(B=16, nv=784, nh=1024), dict(B=5, nv=3, nh=2)])
 def test_small_score_vs_oracle(gpu_device, ctx_option, cfg, local):
     """kurbm_score_small -- the score of fit(verbose=1) for a small RBM in ONE launch (csrc/kurbm_small.hip: k_score_small), both
     schedules -- against the oracle's step_score with the same counters, the free energies against O.free_energy, twice the same
