@@ -32,13 +32,9 @@ for bs in batches:
             eng = DeviceRBM(g.uniform(-0.05, 0.05, (nv, nh)).astype(np.float32), np.zeros(nh, np.float32), np.zeros(nv, np.float32), dev)
             planes = eng.make_planes(V, [(i * bs, bs) for i in range(steps)], mode) if compute == "x3" else None
 
-            def run(n):
-                if compute == "x3":
-                    for i in range(n):
-                        eng.cd_step(V, bs, i * bs, 1e-3 / bs, 1, i, mode=mode, compute="x3", planes=planes)
-                else:
-                    eng.cd_epoch(V, bs * n, bs, 1e-3 / bs, 1, 0, mode=mode, compute=compute)
-            run(10)
+            def run(n):     # (one library call for the n steps, as fit(verbose=0) makes it: the host is not in the way)
+                eng.cd_epoch(V, bs * n, bs, 1e-3 / bs, 1, 0, mode=mode, compute=compute, planes=planes)
+            run(steps)
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
