@@ -6,8 +6,9 @@
  *       -L keras_unsupervised_amd/csrc -lkurbm -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/keras_unsupervised_amd/csrc -o cd_step_demo
  *
  * Runs the same update (784 x 256, 64 rows: the shape of the reference's example, ku/ebm/rbm.py:117-134) on the fp32-MFMA
- * kernels (kurbm_cd_step) and on the x3 kernels (kurbm_cd_step_x3, resident data planes) from the same parameters and
- * counters, and prints how far the two results are apart (fp32 summation order only) -- exit code 0 iff <= 1e-5.
+ * kernels (kurbm_cd_step), on the x3 kernels (kurbm_cd_step_x3, resident data planes) and as ONE launch (kurbm_cd_step_small)
+ * from the same parameters and counters, prints how far the results are apart (fp32 summation order only), and reads the score of
+ * fit(verbose = 1) (kurbm_score_small) by polling pinned host memory -- exit code 0 iff the differences are <= 1e-5.
  */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -69,13 +70,36 @@ int main(void) {
     HIP(hipDeviceSynchronize());
     HIP(hipMemcpy(r2, W, nW * 4, hipMemcpyDeviceToHost));
 
-    double maxdiff = 0.0, moved = 0.0;
+    /* the same update in ONE launch (kurbm_cd_step_small), then the score of fit(verbose = 1) in one more (kurbm_score_small):
+     * the score and a 1.0f behind it land in PINNED host memory, which this thread polls -- no copy, no event, no synchronise */
+    float* r3 = malloc(nW * 4);
+    volatile float* score;
+    HIP(hipHostMalloc((void**)&score, 16, hipHostMallocDefault));
+    score[0] = 0.0f; score[1] = 0.0f;
+    HIP(hipMemcpy(W, hW, nW * 4, hipMemcpyHostToDevice)); HIP(hipMemset(bh, 0, nh * 4)); HIP(hipMemset(bv, 0, nv * 4));
+    o.v_planes = NULL;
+    KU(kurbm_cd_step_small(ctx, &p, v, rows, ld, &o, 7, ws, ws_bytes, NULL));
+    kurbm_cd_opts so = o;
+    so.chain = 3;   /* the score's own chain of draws */
+    KU(kurbm_score_small(ctx, &p, v, rows, ld, &so, (float*)score, NULL, ws, ws_bytes, NULL));
+    long spins = 0;
+    while (score[1] != 1.0f && spins < 2000000000L) ++spins;
+    if (score[1] != 1.0f) { fprintf(stderr, "the score never arrived\n"); return 5; }
+    const float got_score = score[0];
+    HIP(hipDeviceSynchronize());
+    HIP(hipMemcpy(r3, W, nW * 4, hipMemcpyDeviceToHost));
+    int status = -1;
+    KU(kurbm_ctx_status(ctx, &status));
+
+    double maxdiff = 0.0, moved = 0.0, maxdiff_small = 0.0;
     for (size_t i = 0; i < nW; ++i) {
-        double d = fabs((double)r1[i] - (double)r2[i]), m = fabs((double)r1[i] - (double)hW[i]);
+        double d = fabs((double)r1[i] - (double)r2[i]), m = fabs((double)r1[i] - (double)hW[i]), d3 = fabs((double)r1[i] - (double)r3[i]);
         if (d > maxdiff) maxdiff = d;
         if (m > moved) moved = m;
+        if (d3 > maxdiff_small) maxdiff_small = d3;
     }
-    printf("abi %d  max |W_fp32mfma - W_x3| = %.3g  max |W_new - W_old| = %.3g\n", kurbm_abi_version(), maxdiff, moved);
+    printf("abi %d  max |W_fp32mfma - W_x3| = %.3g  max |W_fp32mfma - W_one_launch| = %.3g  max |W_new - W_old| = %.3g  score %.4f (polled, %ld spins)  status %d\n",
+           kurbm_abi_version(), maxdiff, maxdiff_small, moved, got_score, spins, status);
     kurbm_ctx_destroy(ctx);
-    return (maxdiff <= 1e-5 && moved > 1e-4) ? 0 : 1;
+    return (maxdiff <= 1e-5 && maxdiff_small <= 1e-5 && moved > 1e-4 && status == 0 && got_score > 0.0f && got_score < 1e4f) ? 0 : 1;
 }

@@ -518,7 +518,8 @@ def test_dbn_golden(gpu_device, golden_dir, capsys):
 
 def test_c_abi_from_plain_c(gpu_device, tmp_path):
     """The boundary is a C ABI: examples/c/cd_step_demo.c (C99, gcc, HIP runtime API for memory, no Python or PyTorch in the
-    process) runs one CD-1 update on the fp32-MFMA and on the x3 entry points with resident planes and compares them."""
+    process) runs one CD-1 update on the fp32-MFMA entry point, on the x3 entry point with resident planes and as ONE launch
+    (kurbm_cd_step_small), compares them, and reads kurbm_score_small's score by polling pinned host memory."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "keras_unsupervised_amd", "csrc")
@@ -528,7 +529,7 @@ def test_c_abi_from_plain_c(gpu_device, tmp_path):
                     "-lm", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 5" in r.stdout
+    assert "abi 5" in r.stdout and "polled" in r.stdout and "status 0" in r.stdout
 
 
 def test_c_abi_error_behaviour(gpu_device):
