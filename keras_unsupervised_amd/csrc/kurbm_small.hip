@@ -3,9 +3,12 @@
 //
 // At these sizes a step is ~0.1-0.3 GFLOP: the five launches of kurbm_cd_step cost five launch latencies (~75 us per step,
 // tools/bench_example_config.py) for ~3 us of arithmetic.  Here the whole step -- rbm.py:120-134 in the fused form: h_pos sample,
-// v_neg sample, h_neg probabilities, dW / db_h / db_v applied -- is one grid-resident kernel of four phases with a device-scope
-// barrier between them (sense-reversing: a wrapping arrival counter and a generation word in the context's status block; every
-// wait is bounded and reports through kurbm_ctx_status instead of hanging):
+// v_neg sample, h_neg probabilities, dW / db_h / db_v applied -- is one grid-resident kernel of four phases.  Two schedules:
+// `local` (default; the whole device is launched): a 16-row band of the batch stays on ONE XCD through phases 1-3 -- its planes
+// and its barrier words go from CU to CU through that XCD's L2 (plain stores, non-temporal loads) -- and only phase 4 waits for
+// the whole grid; else every phase spans the grid with a device-scope barrier behind it (counters and a generation word in the
+// context's status block).  Every wait is bounded and reports through kurbm_ctx_status instead of hanging.  The score of
+// fit(verbose = 1) is a second kernel on the same schedules (k_score_small, below).
 //   1  h_pos = (u < act(v . W + b_h))            one 16 x 16 output tile per workgroup pass, its eight waves split k
 //   2  v_neg = (u < sigmoid(h_pos . W^T + b_v))  or  loc + N(0, 1)   (Gaussian visibles: Box-Muller of two Philox planes)
 //   3  h_neg = sigmoid(v_neg . W + b_h)
@@ -37,7 +40,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   fences).  The planes that cross a barrier -- h_pos, v_neg, h_neg -- are written by agent-scope (write-through) stores and a wave
 //   drains its stores before it arrives; they are read by agent-scope loads (past this CU's L1 and this XCD's L2), so no acquire
 //   either (one invalidate behind the barrier and plain loads instead: 73 against 53 us per step -- every phase loses its cached W).
-// * Two levels: a workgroup arrives on the counter of its XCD (workgroup i runs on XCD i % 8), the last one of an XCD on the grid's
+// * Two levels: a workgroup arrives on one of eight counters (blockIdx.x % 8: one XCD's share of the grid, or a mix of two -- only the
+//   count matters here), the last one of a counter on the grid's
 //   counter, the last of those bumps the generation word everybody polls -- 256 arrivals on ONE address are 256 serialised atomics
 //   at the memory side (~4 us); 32 on each of eight addresses in parallel, then 8, are not.
 __device__ bool grid_barrier(const SmallArgs& a, unsigned& gen) {
