@@ -8,7 +8,7 @@
 #   sq        SQ / TCC counter passes (waits, LDS conflicts, L2 hit rate, MFMA busy)
 #   score     fit(verbose = 1) against the quiet loop, and the score pass's kernels
 #   config5   one GPU's share of config 5 (time, then its kernels under rocprofv3)
-#   small     the one-launch step of small RBMs against the five-launch path
+#   small     the one-launch step of small RBMs against the five-launch path, and fit(verbose=1) at the reference example's size
 # rocprofv3 gets python3 directly behind `--`, and counters are collected in passes of their own (no trace domains beside --pmc).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=${1:-r04x}; shift
@@ -50,4 +50,5 @@ if has config5; then
 fi
 if has small; then
   python tools/small_times.py 2>&1 | grep -v amdgpu.ids > $O/small_times.txt; cat $O/small_times.txt
+  python tools/verbose_small.py 2>&1 | grep -v amdgpu.ids > $O/verbose_small.txt; cat $O/verbose_small.txt   # fit(verbose=1) at the example's size
 fi
