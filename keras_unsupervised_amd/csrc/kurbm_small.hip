@@ -491,25 +491,34 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_score_small(SmallArgs a) {
     }
     __syncthreads();
     if (!last) return;
-    // |F(v) - F(v')| of every row (a thread per row: the partials of a row tile lie side by side), then a fixed-order tree
+    // |F(v) - F(v')| of every row, four lanes per row (lane q of a quad takes the partials of column tiles q, q + 4, ...: sixteen
+    // requested at a time -- one at a time, one thread per row, this was 65 memory-side round trips in a row, ~40 us), the quad's
+    // four sums added as (s0 + s1) + (s2 + s3); then a fixed-order tree over the rows
     float* sums = red;                                  // 512 floats of the 2048
     float d = 0.f;
-    // (sixteen partials requested at a time: one at a time this loop was 65 memory-side round trips in a row, ~40 us)
-    auto column_sum = [&](const float* part, int ntile, int r, float acc) {
-        for (int t0 = 0; t0 < ntile; t0 += 16) {
+    const int part = threadIdx.x & 3;
+    auto column_sum = [&](const float* part_sums, int ntile, int r, bool live) {
+        float acc = 0.f;
+        for (int t0 = part; t0 < ntile; t0 += 64) {
             float q[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) q[i] = t0 + i < ntile ? ld_plane<1>(part, (unsigned)((t0 + i) * a.ldt + r)) : 0.f;
+            for (int i = 0; i < 16; ++i) q[i] = (live && t0 + 4 * i < ntile) ? ld_plane<1>(part_sums, (unsigned)((t0 + 4 * i) * a.ldt + r)) : 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc += q[i];
         }
+        acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+        acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0x4E, 0xF, 0xF, true));   // lane ^ 2
         return acc;
     };
-    for (int r = threadIdx.x; r < a.rows; r += 64 * SMALL_WAVES) {
-        const float f = column_sum(rp1, tiles_h, r, ld_plane<1>(vb, (unsigned)r));
-        const float f1 = column_sum(rp2, tiles_h, r, column_sum(rpv, tiles_v, r, 0.f));
-        if (a.F) { a.F[r] = -f; a.F[a.rows + r] = -f1; }
-        d += fabsf(f1 - f);                             // |(-f) - (-f1)|
+    for (int r0 = 0; r0 < a.rows; r0 += 16 * SMALL_WAVES) {          // (every lane of a quad makes the same trips)
+        const int r = r0 + ((int)threadIdx.x >> 2);
+        const bool live = r < a.rows;
+        const float fh = column_sum(rp1, tiles_h, r, live), fv1 = column_sum(rpv, tiles_v, r, live), fh1 = column_sum(rp2, tiles_h, r, live);
+        if (live && part == 0) {
+            const float f = ld_plane<1>(vb, (unsigned)r) + fh, f1 = fv1 + fh1;
+            if (a.F) { a.F[r] = -f; a.F[a.rows + r] = -f1; }
+            d += fabsf(f1 - f);                             // |(-f) - (-f1)|
+        }
     }
     sums[threadIdx.x] = d;
     __syncthreads();
