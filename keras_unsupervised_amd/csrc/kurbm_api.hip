@@ -748,6 +748,11 @@ int kurbm_debug_small_stamps(kurbm_ctx* ctx, unsigned long long* out8) {
     HIP_TRY(hipMemcpy(out8, ctx->status + 40, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return KURBM_OK;
 }
+/* ... and the fine stamps of the h -> v phase (workgroup 0, its first pass) */
+int kurbm_debug_small_fine_stamps(kurbm_ctx* ctx, unsigned long long* out8) {
+    HIP_TRY(hipMemcpy(out8, ctx->status + 768, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return KURBM_OK;
+}
 #endif
 #ifdef KURBM_STAMPS
 /* diagnostic library only: not part of include/kurbm.h */

@@ -238,25 +238,38 @@ __device__ __forceinline__ void half_step_tiles(const SmallArgs& a, const float*
         const int tm = LOCAL ? tm0 : u / tiles_n, tn = LOCAL ? u : u - tm * tiles_n;
         const int m = tm * 16 + x, n = tn * 16 + x;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#ifdef KURBM_SMALL_STAMPS
+#define KURBM_FST(i) do { if (HV && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.status + 768)[i] = realtime_ticks(); } while (0)
+#else
+#define KURBM_FST(i) do { } while (0)
+#endif
+        KURBM_FST(0);
+        // (requested here: in the epilogue its latency -- an L2 round trip -- would be exposed, 0.5 us of every phase)
+        const float bias_col = (wsub == 0 && live && n < N) ? bias[n] : 0.f;
+        // ... and the finishing wave's Philox blocks do not depend on the product: drawn now, under the operand loads' latency
+        uint32_t w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
+        if (wsub == 0 && live && n < N && noise != NOISE_NONE) {
+            const uint64_t grow = rng.row0 + (uint64_t)(tm * 16 + 4 * slot);
+            philox4x32_10((uint32_t)n, (uint32_t)(grow >> 2), rng.stream_id, rng.step, rng.seed_lo, rng.seed_hi, w1);
+            if (noise == NOISE_GAUSSIAN)
+                philox4x32_10((uint32_t)n, (uint32_t)(grow >> 2), rng.stream_id | 0x80000000u, rng.step, rng.seed_lo, rng.seed_hi, w2);
+        }
         if (live) {
             const float* At = in + (size_t)tm * 16 * ld_in;                                      // rows of the batch, k contiguous
             if (HV) tile_mma<true, true, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + (size_t)tn * 16 * a.ldw, a.ldw, n < N, K, wsub, nch, kw, x, slot);   // W^T: rows = visible units
             else    tile_mma<true, false, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + tn * 16, a.ldw, n < N, K, wsub, nch, kw, x, slot);                 // W as [k][n]
         }
         *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc;
+        KURBM_FST(1);
         __syncthreads();
+        KURBM_FST(2);
         if (wsub == 0 && live) {
             f32x4 s = *reinterpret_cast<const f32x4*>(red + (wave * 64 + lane) * 4);
             for (int w = 1; w < kw; ++w) s += *reinterpret_cast<const f32x4*>(red + ((wave + w) * 64 + lane) * 4);
             const int col = tn * 16 + x, row0 = tm * 16 + 4 * slot;     // C layout: lane holds rows row0 .. row0 + 3 of column col
             f32x4 rp = {0.f, 0.f, 0.f, 0.f};
             if (col < N) {
-                const float b = bias[col];
-                uint32_t w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
-                const uint64_t grow = rng.row0 + (uint64_t)row0;
-                if (noise != NOISE_NONE) philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), rng.stream_id, rng.step, rng.seed_lo, rng.seed_hi, w1);
-                if (noise == NOISE_GAUSSIAN)
-                    philox4x32_10((uint32_t)col, (uint32_t)(grow >> 2), rng.stream_id | 0x80000000u, rng.step, rng.seed_lo, rng.seed_hi, w2);
+                const float b = bias_col;                                   // (col == n, row0 == tm * 16 + 4 * slot: the draws above)
                 f32x4 yt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -280,7 +293,9 @@ __device__ __forceinline__ void half_step_tiles(const SmallArgs& a, const float*
                 if (x == 0) st_plane4(rowpart, 4u * (unsigned)(tn * a.ldt + row0), rp);
             }
         }
+        KURBM_FST(3);
         __syncthreads();
+        KURBM_FST(4);
     }
 }
 
@@ -301,6 +316,11 @@ __device__ __forceinline__ void half_step_small(const SmallArgs& a, const float*
     half_step_tiles<HV, IN_PL, OUT_SC, LOCAL, false, RP>(a, in, ld_in, out, ldo, outT, act, noise, rng, red, rowpart, grp);
 }
 
+#ifdef KURBM_SMALL_STAMPS   // diagnostic build: phase boundaries of workgroup 0 (100 MHz ticks) into words 40.. of the status block
+#define KURBM_SST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.status + 40)[i] = realtime_ticks(); } while (0)
+#else
+#define KURBM_SST(i) do { } while (0)
+#endif
 template <bool LOCAL>
 __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
     __shared__ __attribute__((aligned(16))) float red[SMALL_WAVES * 64 * 4];
@@ -309,11 +329,6 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
     gen = __builtin_amdgcn_readfirstlane(gen);   // (only thread 0 uses it; uniform for tidiness)
     const int act_h = a.gauss ? ACT_RELU : ACT_SIGMOID, act_v = a.gauss ? ACT_LINEAR : ACT_SIGMOID;
     bool ok = true;
-#ifdef KURBM_SMALL_STAMPS   // diagnostic build: phase boundaries of workgroup 0 (100 MHz ticks) into words 40.. of the status block
-#define KURBM_SST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.status + 40)[i] = realtime_ticks(); } while (0)
-#else
-#define KURBM_SST(i) do { } while (0)
-#endif
     KURBM_SST(0);
     if constexpr (LOCAL) {
         // The `local` schedule: row tile tm of phases 1-3 belongs to the workgroups of XCD tm % 8, which hand h_pos and v_neg to
@@ -459,14 +474,20 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_score_small(SmallArgs a) {
             ggen = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(d, 4 * rank, 0, 2);
         }
         ggen = __shfl(ggen, 0);
+        KURBM_SST(0);
         half_step_small<false, 0, 2, true, 1>(a, a.v, a.ldv, a.h_pos, a.ldh, nullptr, act_h, NOISE_BERNOULLI, a.rng_h, red, rp1, grp);
         if (rank == ngrp - 1)
             for (int tm = grp; tm < tiles_m; tm += 8)
                 for (int r = tm * 16 + wave; r < tm * 16 + 16 && r < a.rows; r += SMALL_WAVES) data_dot(r);
+        KURBM_SST(1);
         ok = group_barrier(a, grp, ggen + 1u) && ok;
+        KURBM_SST(2);
         if (ok) half_step_small<true, 2, 2, true, 2>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, nullptr, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red, rpv, grp);
+        KURBM_SST(3);
         ok = group_barrier(a, grp, ggen + 2u) && ok;
+        KURBM_SST(4);
         if (ok) half_step_small<false, 2, 2, true, 1>(a, a.v_neg, a.ldn, nullptr, 0, nullptr, ACT_LINEAR, NOISE_NONE, a.rng_h, red, rp2, grp);
+        KURBM_SST(5);
     } else {
         unsigned gen = 0;
         if (threadIdx.x == 0) gen = __hip_atomic_load(a.bar + 16 * 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -490,6 +511,9 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_score_small(SmallArgs a) {
         if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+#ifdef KURBM_SMALL_STAMPS   // (the last workgroup's own stamps: when it found itself last, when the score was stored)
+    if (last && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.status + 40)[6] = realtime_ticks();
+#endif
     if (!last) return;
     // |F(v) - F(v')| of every row, four lanes per row (lane q of a quad takes the partials of column tiles q, q + 4, ...: sixteen
     // requested at a time -- one at a time, one thread per row, this was 65 memory-side round trips in a row, ~40 us), the quad's
@@ -532,6 +556,9 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_score_small(SmallArgs a) {
         const float sc = ok ? sums[0] / (float)a.rows : __builtin_nanf("");
         const unsigned long long both = (unsigned long long)__float_as_uint(sc) | ((unsigned long long)__float_as_uint(1.0f) << 32);
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.score), both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef KURBM_SMALL_STAMPS
+        reinterpret_cast<unsigned long long*>(a.status + 40)[7] = realtime_ticks();
+#endif
     }
 }
 
