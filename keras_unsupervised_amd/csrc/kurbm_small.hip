@@ -44,7 +44,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   count matters here), the last one of a counter on the grid's
 //   counter, the last of those bumps the generation word everybody polls -- 256 arrivals on ONE address are 256 serialised atomics
 //   at the memory side (~4 us); 32 on each of eight addresses in parallel, then 8, are not.
-__device__ bool grid_barrier(const SmallArgs& a, unsigned& gen) {
+__device__ __forceinline__ bool grid_barrier(const SmallArgs& a, unsigned& gen) {
     __shared__ int ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -96,7 +96,7 @@ __device__ __forceinline__ int xcc_of_workgroup() {
 // loads, a lane per workgroup, until every word has reached that number -- one L2 round trip to arrive, one per poll (0.24 us
 // each: xcd_l2_probe) where the grid's barrier pays three memory-side ones.  A wave has drained its plane stores before it
 // arrives.  The numbers only grow (signed differences); a timeout reports through the status word like the grid barrier's.
-__device__ bool group_barrier(const SmallArgs& a, int g, unsigned target) {
+__device__ __forceinline__ bool group_barrier(const SmallArgs& a, int g, unsigned target) {
     __shared__ int gok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -316,6 +316,33 @@ __device__ __forceinline__ void half_step_small(const SmallArgs& a, const float*
     half_step_tiles<HV, IN_PL, OUT_SC, LOCAL, false, RP>(a, in, ld_in, out, ldo, outT, act, noise, rng, red, rowpart, grp);
 }
 
+// Phase 1 is done on every XCD (eight agent-scope words, each set by the first workgroup of a group behind the group's first
+// barrier): the wait of a workgroup that takes the positive half of its phase-4 tile early.  Bounded; workgroup-uniform result.
+__device__ __forceinline__ bool early_wait(const SmallArgs& a, unsigned* done1, unsigned target) {
+    __shared__ int eok;
+    if (threadIdx.x < 64) {
+        const unsigned long long t0 = realtime_ticks();
+        bool seen = false;
+        for (;;) {
+            const unsigned f = threadIdx.x < 8 ? __hip_atomic_load(done1 + 16 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+            if (__all((int)(f - target) >= 0)) { seen = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+            if (realtime_ticks() - t0 > a.timeout_ticks) break;
+        }
+        if (threadIdx.x == 0) eok = seen ? 1 : 0;
+    }
+    __syncthreads();
+    const bool r = eok != 0;
+    __syncthreads();                                   // (eok may be written again by a second wait)
+    return r;
+}
+
+// v_pos^T . h_pos of the 16 x 16 tile of W that is phase 4's task `task` (rbm.py:125: the positive half of dW), k = the batch rows
+__device__ __forceinline__ void positive_product(f32x4& acc, const SmallArgs& a, int task, int tiles_h, int nch, int x, int slot) {
+    const int ti = task / tiles_h, tj = task - ti * tiles_h;
+    tile_mma<false, true, false, 0, 1>(acc, a.v + ti * 16, a.ldv, ti * 16 + x < a.n_vis, a.h_posT + (size_t)tj * 16 * a.ldt, a.ldt, tj * 16 + x < a.n_hid, a.rows, 0, nch, 1, x, slot);
+}
+
 #ifdef KURBM_SMALL_STAMPS   // diagnostic build: phase boundaries of workgroup 0 (100 MHz ticks) into words 40.. of the status block
 #define KURBM_SST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.status + 40)[i] = realtime_ticks(); } while (0)
 #else
@@ -329,6 +356,16 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
     gen = __builtin_amdgcn_readfirstlane(gen);   // (only thread 0 uses it; uniform for tidiness)
     const int act_h = a.gauss ? ACT_RELU : ACT_SIGMOID, act_v = a.gauss ? ACT_LINEAR : ACT_SIGMOID;
     bool ok = true;
+    // phase 4's tasks, one per wave: the 16 x 16 tiles of W, then 16-column groups of db_h and db_v.  LOCAL: dealt from the LAST
+    // workgroup down -- the high ranks of every XCD's group have no tile in phases 1-3, so a wave there can take the positive half
+    // of its tile's statistics (v_pos^T . h_pos: ready once phase 1 is done everywhere) while the others run phases 2 and 3
+    const int lane = threadIdx.x & 63, x = lane & 15, slot = lane >> 4;
+    const int tiles_v = (a.n_vis + 15) / 16, tiles_h = (a.n_hid + 15) / 16, nch = (a.rows + 15) / 16;
+    const int n_w = (a.which & 1) ? tiles_v * tiles_h : 0, n_bh = (a.which & 2) ? tiles_h : 0, n_bv = (a.which & 4) ? tiles_v : 0;
+    const int nwaves = gridDim.x * SMALL_WAVES;
+    const int task0 = (LOCAL ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * SMALL_WAVES + (threadIdx.x >> 6);
+    f32x4 acc_early = {0.f, 0.f, 0.f, 0.f};
+    bool have_early = false;
     KURBM_SST(0);
     if constexpr (LOCAL) {
         // The `local` schedule: row tile tm of phases 1-3 belongs to the workgroups of XCD tm % 8, which hand h_pos and v_neg to
@@ -346,10 +383,30 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
         KURBM_SST(1);
         ok = group_barrier(a, grp, ggen + 1u) && ok;
         KURBM_SST(2);
+        unsigned* done1 = a.bar + 464;                     // eight words, 64 bytes apart: "phase 1 is done on XCD g"
+        bool idle2 = false, idle3 = false;
+        const bool wg_has_w_task = (int)(task0 - (threadIdx.x >> 6)) < n_w;     // (workgroup-uniform: its first wave's task is a tile of W)
+        {
+            // "phase 1 is done on XCD grp" for everybody (its transposed plane was drained at agent scope before the barrier)
+            const int rank = blockIdx.x >> 3, ngrp = (int)gridDim.x >> 3;
+            if (ok && rank == 0 && threadIdx.x == 0) __hip_atomic_store(done1 + 16 * grp, ggen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // does this workgroup have a tile in phase 2?  (half_step_small's rule: two tiles per pass where that saves a pass)
+            const int nch2 = tiles_h, two = (nch2 <= 32 && (tiles_v + 2 * ngrp - 1) / (2 * ngrp) < (tiles_v + ngrp - 1) / ngrp) ? 2 : 1;
+            idle2 = rank >= (tiles_v + two - 1) / two;
+            idle3 = rank >= tiles_h;
+            if (ok && idle2 && wg_has_w_task) {
+                ok = early_wait(a, done1, ggen + 1u);
+                if (ok && task0 < n_w) { positive_product(acc_early, a, task0, tiles_h, nch, x, slot); have_early = true; }
+            }
+        }
         if (ok) half_step_small<true, 2, 2, true>(a, a.h_pos, a.ldh, a.v_neg, a.ldn, a.v_negT, act_v, a.gauss ? NOISE_GAUSSIAN : NOISE_BERNOULLI, a.rng_v, red, nullptr, grp);
         KURBM_SST(3);
         ok = group_barrier(a, grp, ggen + 2u) && ok;
         KURBM_SST(4);
+        if (ok && !idle2 && idle3 && wg_has_w_task) {      // (busy in phase 2, idle in phase 3: the positive half now)
+            ok = early_wait(a, done1, ggen + 1u);
+            if (ok && task0 < n_w) { positive_product(acc_early, a, task0, tiles_h, nch, x, slot); have_early = true; }
+        }
         if (ok) half_step_small<false, 2, 2, true>(a, a.v_neg, a.ldn, nullptr, 0, a.h_negT, ACT_SIGMOID, NOISE_NONE, a.rng_h, red, nullptr, grp);
         KURBM_SST(5);
         ok = grid_barrier(a, gen) && ok;
@@ -375,12 +432,8 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
         if (threadIdx.x == 0) __hip_atomic_fetch_or(a.status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    // 4: the statistics, applied.  Tasks, one per wave: the 16 x 16 tiles of W, then 16-column groups of db_h and db_v
-    const int lane = threadIdx.x & 63, x = lane & 15, slot = lane >> 4;
-    const int tiles_v = (a.n_vis + 15) / 16, tiles_h = (a.n_hid + 15) / 16, nch = (a.rows + 15) / 16;
-    const int n_w = (a.which & 1) ? tiles_v * tiles_h : 0, n_bh = (a.which & 2) ? tiles_h : 0, n_bv = (a.which & 4) ? tiles_v : 0;
-    const int nwaves = gridDim.x * SMALL_WAVES;
-    for (int task = blockIdx.x * SMALL_WAVES + (threadIdx.x >> 6); task < n_w + n_bh + n_bv; task += nwaves) {
+    // 4: the statistics, applied
+    for (int task = task0; task < n_w + n_bh + n_bv; task += nwaves) {
         if (task < n_w) {
             const int ti = task / tiles_h, tj = task - ti * tiles_h;
             const int i = ti * 16 + x, j = tj * 16 + x;
@@ -391,7 +444,8 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
             for (int r = 0; r < 4; ++r) wv[r] = (col < a.n_hid && row0 + r < a.n_vis) ? a.W[(size_t)(row0 + r) * a.ldw + col] : 0.f;
             // dW = v_pos^T . h_pos - v_neg^T . h_neg   (rbm.py:125-126), k = the batch rows: contiguous in the transposed planes, strided
             // in the data.  (One batch of loads per product.  Both products' loads in ONE batch: 15.0 against 8.3 us for this phase.)
-            tile_mma<false, true, false, 0, 1>(acc, a.v + ti * 16, a.ldv, i < a.n_vis, a.h_posT + (size_t)tj * 16 * a.ldt, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+            if (have_early && task == task0) acc = acc_early;       // (the positive half was done beside phases 2 and 3: same MFMAs, same order)
+            else positive_product(acc, a, task, tiles_h, nch, x, slot);
             tile_mma<true, true, true, 1, 1>(acc, a.v_negT + (size_t)ti * 16 * a.ldt, a.ldt, i < a.n_vis, a.h_negT + (size_t)tj * 16 * a.ldt, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
             if (col < a.n_hid)
 #pragma unroll
