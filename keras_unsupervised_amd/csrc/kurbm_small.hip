@@ -16,6 +16,8 @@
 //      slabs); the bias column sums by waves of their own, fixed order (bit-reproducible).  Phases 1-3 leave their planes
 //      TRANSPOSED as well ([unit][batch row]: the four rows a lane holds are one 16-byte store), so that k = the batch is
 //      contiguous here: 16-byte loads instead of four strided dwords per operand and chunk
+//      (`local` schedule: the tasks are dealt from the last workgroup down, and a workgroup with no tile in phase 2 or 3 computes the
+//      positive half of its tile there, as soon as phase 1 is done on every XCD)
 // Products on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fma chains, like kurbm_kernels.hip), operands straight
 // from L2 -- the whole problem is a few MB -- with the same k-slot permutation trick: a lane's four consecutive k feed four
 // successive MFMAs.  Same Philox counters as every other path (include/kurbm.h), so the draws are the oracle's; the sums are
