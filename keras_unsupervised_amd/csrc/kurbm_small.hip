@@ -411,7 +411,17 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
         }
         if (ok) half_step_small<false, 2, 2, true>(a, a.v_neg, a.ldn, nullptr, 0, a.h_negT, ACT_SIGMOID, NOISE_NONE, a.rng_h, red, nullptr, grp);
         KURBM_SST(5);
-        ok = grid_barrier(a, gen) && ok;
+        // In front of phase 4, not the grid's counter barrier (four memory-side trips in a row) but: the band's own barrier, a
+        // "phase 3 done on XCD g" word from the group's first workgroup, and the workgroups that HAVE a task wait for the eight
+        // words (one trip to publish, one per poll); the others are done.  Nobody writes W before every XCD is through phase 3.
+        ok = group_barrier(a, grp, ggen + 3u) && ok;
+        {
+            unsigned* done3 = a.bar + 472;                 // (the other half of done1's 64-byte lines)
+            if (ok && (blockIdx.x >> 3) == 0 && threadIdx.x == 0) __hip_atomic_store(done3 + 16 * grp, ggen + 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ok && (int)(task0 - (threadIdx.x >> 6)) >= n_w + n_bh + n_bv) return;     // (workgroup-uniform: no task for its first wave, none for the others)
+            if (ok) ok = early_wait(a, done3, ggen + 3u);
+        }
+        (void)gen;
         KURBM_SST(6);
     } else {
         // 1: h_pos ~ p(h | v_pos)                                                   rbm.py:120
