@@ -587,14 +587,22 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_score_small(SmallArgs a) {
     float* sums = red;                                  // 512 floats of the 2048
     float d = 0.f;
     const int part = threadIdx.x & 3;
-    auto column_sum = [&](const float* part_sums, int ntile, int r, bool live) {
+    // (the first sixteen partials of all three sums -- all of them up to 1024 units a side -- and v . b_v are requested together: one
+    //  memory-side round trip instead of four in a row)
+    auto first16 = [&](float (&q)[16], const float* part_sums, int ntile, int r, bool live) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q[i] = (live && part + 4 * i < ntile) ? ld_plane<1>(part_sums, (unsigned)((part + 4 * i) * a.ldt + r)) : 0.f;
+    };
+    auto finish = [&](const float (&q)[16], const float* part_sums, int ntile, int r, bool live) __attribute__((always_inline)) {
         float acc = 0.f;
-        for (int t0 = part; t0 < ntile; t0 += 64) {
-            float q[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) q[i] = (live && t0 + 4 * i < ntile) ? ld_plane<1>(part_sums, (unsigned)((t0 + 4 * i) * a.ldt + r)) : 0.f;
+        for (int i = 0; i < 16; ++i) acc += q[i];
+        for (int t0 = part + 64; t0 < ntile; t0 += 64) {      // (more than 64 column tiles: the rest, sixteen at a time)
+            float q2[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc += q[i];
+            for (int i = 0; i < 16; ++i) q2[i] = (live && t0 + 4 * i < ntile) ? ld_plane<1>(part_sums, (unsigned)((t0 + 4 * i) * a.ldt + r)) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc += q2[i];
         }
         acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xF, 0xF, true));   // lane ^ 1
         acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0x4E, 0xF, 0xF, true));   // lane ^ 2
@@ -603,9 +611,12 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_score_small(SmallArgs a) {
     for (int r0 = 0; r0 < a.rows; r0 += 16 * SMALL_WAVES) {          // (every lane of a quad makes the same trips)
         const int r = r0 + ((int)threadIdx.x >> 2);
         const bool live = r < a.rows;
-        const float fh = column_sum(rp1, tiles_h, r, live), fv1 = column_sum(rpv, tiles_v, r, live), fh1 = column_sum(rp2, tiles_h, r, live);
+        float qa[16], qb[16], qc[16];
+        first16(qa, rp1, tiles_h, r, live); first16(qb, rpv, tiles_v, r, live); first16(qc, rp2, tiles_h, r, live);
+        const float dot = (live && part == 0) ? ld_plane<1>(vb, (unsigned)r) : 0.f;
+        const float fh = finish(qa, rp1, tiles_h, r, live), fv1 = finish(qb, rpv, tiles_v, r, live), fh1 = finish(qc, rp2, tiles_h, r, live);
         if (live && part == 0) {
-            const float f = ld_plane<1>(vb, (unsigned)r) + fh, f1 = fv1 + fh1;
+            const float f = dot + fh, f1 = fv1 + fh1;
             if (a.F) { a.F[r] = -f; a.F[a.rows + r] = -f1; }
             d += fabsf(f1 - f);                             // |(-f) - (-f1)|
         }
