@@ -160,14 +160,15 @@ __device__ __forceinline__ void st_plane4(float* base, unsigned byte_off, f32x4 
 // x_ok / k < K guard ragged shapes (zeros contribute nothing).  NEG: the A values enter negated.
 // A and B point at the TILE (KC: its first row; KS: its first column), so x = lane & 15 indexes both.
 // A_PL / B_PL: the operand is a plane another workgroup wrote in an earlier phase -- loads of scope 1 (agent) or 2 (its XCD).
-template <bool A_KC, bool B_KC, bool NEG, int A_PL = 0, int B_PL = 0>
+template <bool A_KC, bool B_KC, bool NEG, int A_PL = 0, int B_PL = 0, int UN = 8>
 __device__ __forceinline__ void tile_mma(f32x4& acc, const float* __restrict__ A, int lda, bool a_ok, const float* __restrict__ B, int ldb, bool b_ok,
                                          int K, int c0, int c1, int cs, int x, int slot) {
     // UN chunks at a time: ALL their loads are issued before the first MFMA -- the operands come from L2 with a few waves per CU, so
     // a chunk-by-chunk loop would pay one L2 round trip per chunk.  (Built and measured TWICE, round 4, and NOT kept: every load
     // unconditional on clamped indices with a select behind it -- 222 branches instead of 641, but hipcc then waits for the loads one
     // by one (200 s_waitcnt vmcnt instead of 46): phase 1 took 20.5 instead of 5.6 us.  The guarded form keeps its loads in flight.)
-    constexpr int UN = 8;
+    // (UN = 2 or 4 where a wave has no more chunks than that -- h -> v of a narrow hidden layer: the dead chunks of an unrolled eight
+    //  would still issue their MFMAs, on zeros)
     for (int cb = c0; cb < c1; cb += UN * cs) {
         float av[UN][4], bv[UN][4];
 #pragma unroll
@@ -258,7 +259,12 @@ __device__ __forceinline__ void half_step_tiles(const SmallArgs& a, const float*
         }
         if (live) {
             const float* At = in + (size_t)tm * 16 * ld_in;                                      // rows of the batch, k contiguous
-            if (HV) tile_mma<true, true, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + (size_t)tn * 16 * a.ldw, a.ldw, n < N, K, wsub, nch, kw, x, slot);   // W^T: rows = visible units
+            if (HV) {                                                                            // W^T: rows = visible units
+                const float* Bt = a.W + (size_t)tn * 16 * a.ldw;
+                if (nch <= 2 * kw) tile_mma<true, true, false, IN_PL, 0, 2>(acc, At, ld_in, m < a.rows, Bt, a.ldw, n < N, K, wsub, nch, kw, x, slot);
+                else if (nch <= 4 * kw) tile_mma<true, true, false, IN_PL, 0, 4>(acc, At, ld_in, m < a.rows, Bt, a.ldw, n < N, K, wsub, nch, kw, x, slot);
+                else tile_mma<true, true, false, IN_PL>(acc, At, ld_in, m < a.rows, Bt, a.ldw, n < N, K, wsub, nch, kw, x, slot);
+            }
             else    tile_mma<true, false, false, IN_PL>(acc, At, ld_in, m < a.rows, a.W + tn * 16, a.ldw, n < N, K, wsub, nch, kw, x, slot);                 // W as [k][n]
         }
         *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc;
