@@ -345,10 +345,22 @@ __device__ __forceinline__ bool early_wait(const SmallArgs& a, unsigned* done1, 
     return r;
 }
 
-// v_pos^T . h_pos of the 16 x 16 tile of W that is phase 4's task `task` (rbm.py:125: the positive half of dW), k = the batch rows
-__device__ __forceinline__ void positive_product(f32x4& acc, const SmallArgs& a, int task, int tiles_h, int nch, int x, int slot) {
+// v_pos^T . h_pos of the 16 x 16 tile of W that is phase 4's task `task` (rbm.py:125: the positive half of dW), k = the batch rows.
+// NOT inlined (three call sites, two unroll variants each: inlined, the kernel ran out of registers), and handed plain values, not
+// the argument struct (a struct passed by reference to a real call is kept in scratch).
+__device__ __attribute__((noinline)) f32x4 positive_product_fn(const float* v, int ldv, int n_vis, const float* h_posT, int ldt, int n_hid,
+                                                                int rows, int task, int tiles_h, int nch, int x, int slot) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int ti = task / tiles_h, tj = task - ti * tiles_h;
-    tile_mma<false, true, false, 0, 1>(acc, a.v + ti * 16, a.ldv, ti * 16 + x < a.n_vis, a.h_posT + (size_t)tj * 16 * a.ldt, a.ldt, tj * 16 + x < a.n_hid, a.rows, 0, nch, 1, x, slot);
+    const float* A = v + ti * 16;
+    const float* B = h_posT + (size_t)tj * 16 * ldt;
+    const bool a_ok = ti * 16 + x < n_vis, b_ok = tj * 16 + x < n_hid;
+    if (nch <= 4) tile_mma<false, true, false, 0, 1, 4>(acc, A, ldv, a_ok, B, ldt, b_ok, rows, 0, nch, 1, x, slot);   // (batches up to 64 rows)
+    else tile_mma<false, true, false, 0, 1>(acc, A, ldv, a_ok, B, ldt, b_ok, rows, 0, nch, 1, x, slot);
+    return acc;
+}
+__device__ __forceinline__ void positive_product(f32x4& acc, const SmallArgs& a, int task, int tiles_h, int nch, int x, int slot) {
+    acc = positive_product_fn(a.v, a.ldv, a.n_vis, a.h_posT, a.ldt, a.n_hid, a.rows, task, tiles_h, nch, x, slot);
 }
 
 #ifdef KURBM_SMALL_STAMPS   // diagnostic build: phase boundaries of workgroup 0 (100 MHz ticks) into words 40.. of the status block
@@ -464,7 +476,12 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
             // in the data.  (One batch of loads per product.  Both products' loads in ONE batch: 15.0 against 8.3 us for this phase.)
             if (have_early && task == task0) acc = acc_early;       // (the positive half was done beside phases 2 and 3: same MFMAs, same order)
             else positive_product(acc, a, task, tiles_h, nch, x, slot);
-            tile_mma<true, true, true, 1, 1>(acc, a.v_negT + (size_t)ti * 16 * a.ldt, a.ldt, i < a.n_vis, a.h_negT + (size_t)tj * 16 * a.ldt, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+            {
+                const float* An = a.v_negT + (size_t)ti * 16 * a.ldt;
+                const float* Bn = a.h_negT + (size_t)tj * 16 * a.ldt;
+                if (nch <= 4) tile_mma<true, true, true, 1, 1, 4>(acc, An, a.ldt, i < a.n_vis, Bn, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+                else tile_mma<true, true, true, 1, 1>(acc, An, a.ldt, i < a.n_vis, Bn, a.ldt, j < a.n_hid, a.rows, 0, nch, 1, x, slot);
+            }
             if (col < a.n_hid)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
