@@ -234,11 +234,14 @@ __device__ __forceinline__ void half_step_tiles(const SmallArgs& a, const float*
     constexpr int per = TWO ? 2 : 1, kw = TWO ? 4 : SMALL_WAVES;
     const int sub = TWO ? (wave >> 2) : 0, wsub = TWO ? (wave & 3) : wave;
     const int nslots = (units + per - 1) / per;
-    for (int tm0 = LOCAL ? grp : 0; tm0 < (LOCAL ? tiles_m : 1); tm0 += 8)
-    for (int q = LOCAL ? rank : (int)blockIdx.x; q < nslots; q += cap) {
+    // LOCAL: the slots of ALL row tiles of this XCD (grp, grp + 8, ...) form one list dealt over its ranks -- at batch 256 the 16
+    // tiles of a v -> h phase take one pass on 16 workgroups, not two passes on eight
+    const int n_rt = LOCAL ? (tiles_m - grp + 7) / 8 : 1;
+    for (int uq = LOCAL ? rank : (int)blockIdx.x; uq < n_rt * nslots; uq += cap) {
+        const int rt = LOCAL ? uq / nslots : 0, q = uq - rt * nslots;
         const int u = q * per + sub;                       // this wave's tile among the units
         const bool live = !TWO || u < units;
-        const int tm = LOCAL ? tm0 : u / tiles_n, tn = LOCAL ? u : u - tm * tiles_n;
+        const int tm = LOCAL ? grp + 8 * rt : u / tiles_n, tn = LOCAL ? u : u - tm * tiles_n;
         const int m = tm * 16 + x, n = tn * 16 + x;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #ifdef KURBM_SMALL_STAMPS
@@ -307,6 +310,13 @@ __device__ __forceinline__ void half_step_tiles(const SmallArgs& a, const float*
     }
 }
 
+// h -> v: two tiles per pass (four waves each) where that saves a pass over the list of a dealer's slots -- n_rt row tiles of `units`
+// column tiles over `cap` workgroups -- and k is short (nch chunks of 16)
+__device__ __forceinline__ bool two_tiles_per_pass(int n_rt, int units, int cap, int nch) {
+    const int one = n_rt * units, two = n_rt * ((units + 1) / 2);
+    return nch <= 32 && (two + cap - 1) / cap < (one + cap - 1) / cap;
+}
+
 // (TWO tiles per pass where that saves a pass and k is short -- decided the same way by every workgroup of the grid)
 template <bool HV, int IN_PL, int OUT_SC, bool LOCAL, int RP = 0>
 __device__ __forceinline__ void half_step_small(const SmallArgs& a, const float* __restrict__ in, int ld_in, float* __restrict__ out, int ldo,
@@ -314,9 +324,8 @@ __device__ __forceinline__ void half_step_small(const SmallArgs& a, const float*
                                                 float* __restrict__ rowpart = nullptr, int grp = 0) {
     if constexpr (HV) {
         const int tiles_m = (a.rows + 15) / 16, tiles_n = (a.n_vis + 15) / 16, nch = (a.n_hid + 15) / 16;
-        const int ngrp = (int)gridDim.x >> 3;
-        const int units = LOCAL ? tiles_n : tiles_m * tiles_n, cap = LOCAL ? ngrp : (int)gridDim.x;
-        if (nch <= 32 && (units + 2 * cap - 1) / (2 * cap) < (units + cap - 1) / cap) {
+        const int n_rt = LOCAL ? (tiles_m - grp + 7) / 8 : 1;
+        if (two_tiles_per_pass(n_rt, LOCAL ? tiles_n : tiles_m * tiles_n, LOCAL ? (int)gridDim.x >> 3 : (int)gridDim.x, nch)) {
             half_step_tiles<HV, IN_PL, OUT_SC, LOCAL, true, RP>(a, in, ld_in, out, ldo, outT, act, noise, rng, red, rowpart, grp);
             return;
         }
@@ -411,9 +420,10 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void k_cd1_small(SmallArgs a) {
             const int rank = blockIdx.x >> 3, ngrp = (int)gridDim.x >> 3;
             if (ok && rank == 0 && threadIdx.x == 0) __hip_atomic_store(done1 + 16 * grp, ggen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // does this workgroup have a tile in phase 2?  (half_step_small's rule: two tiles per pass where that saves a pass)
-            const int nch2 = tiles_h, two = (nch2 <= 32 && (tiles_v + 2 * ngrp - 1) / (2 * ngrp) < (tiles_v + ngrp - 1) / ngrp) ? 2 : 1;
-            idle2 = rank >= (tiles_v + two - 1) / two;
-            idle3 = rank >= tiles_h;
+            const int n_rt = ((a.rows + 15) / 16 - grp + 7) / 8;      // row tiles of this XCD: its phase-2 / phase-3 slots are dealt over the ranks
+            const int two = two_tiles_per_pass(n_rt, tiles_v, ngrp, tiles_h) ? 2 : 1;
+            idle2 = rank >= n_rt * ((tiles_v + two - 1) / two);
+            idle3 = rank >= n_rt * tiles_h;
             if (ok && idle2 && wg_has_w_task) {
                 ok = early_wait(a, done1, ggen + 1u);
                 if (ok && task0 < n_w) { positive_product(acc_early, a, task0, tiles_h, nch, x, slot); have_early = true; }

@@ -393,7 +393,7 @@ class RBM(object):
         """The compute path of this fit.  'auto' reads tools/small_crossover.py's tables (784 visible units, one MI355X;
         profiles/r04_e_compute_path_crossover.txt):
         * the one-launch step (CD-1 from the data, one GPU) up to batch 128 with up to 1024 hidden units, batch 256 with up to 512 and
-          batch 384 with up to 256 -- 21-54 us per step where the multi-launch paths take 55-110;
+          batch 384 with up to 256, batch 512 with up to 128 -- 21-56 us per step where the multi-launch paths take 55-110;
         * 0/1 data in Bernoulli mode: x3 at every other size (it beats the fp32-MFMA launches from batch 64 on);
         * real-valued data or Gaussian visibles (three pieces per value, seven launches): x3 from rows x n_vis x n_hid >= 6e8 on
           (batch 1024 at 784 x 1024, 1536 at 784 x 512), the fp32-MFMA kernels below."""
@@ -401,7 +401,7 @@ class RBM(object):
         small_ok = self.cd_k == 1 and not self.persistent and dp.world()[1] == 1
         if c == "auto":
             b, h = int(self.hps["batch_size"]), int(self.output_dim)
-            if small_ok and ((b <= 128 and h <= 1024) or (b <= 256 and h <= 512) or (b <= 384 and h <= 256)):
+            if small_ok and ((b <= 128 and h <= 1024) or (b <= 256 and h <= 512) or (b <= 384 and h <= 256) or (b <= 512 and h <= 128)):
                 return "small"
             real = self.mode == MODE_VISIBLE_GAUSSIAN or getattr(self, "_data_real", False)
             n_vis = self._dev.n_vis if self._dev is not None else 784
